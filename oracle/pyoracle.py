@@ -1,0 +1,264 @@
+"""ctypes front-end of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under polycap_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_double_p = C.POINTER(C.c_double)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+    def tup(self):
+        return (self.x, self.y, self.z)
+
+
+class OpticS(C.Structure):
+    _fields_ = [("nmax", C.c_int), ("z", c_double_p), ("cap", c_double_p), ("ext", c_double_p),
+                ("sig_rough", C.c_double), ("n_cap", C.c_int64), ("density", C.c_double)]
+
+
+class SourceS(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("d_source", "src_x", "src_y", "src_sigx", "src_sigy",
+                                          "src_shiftx", "src_shifty", "hor_pol")]
+
+
+class PhotonS(C.Structure):
+    _fields_ = [("start_coords", Vec3), ("start_direction", Vec3), ("start_electric_vector", Vec3),
+                ("exit_coords", Vec3), ("exit_direction", Vec3), ("exit_electric_vector", Vec3),
+                ("src_start_coords", Vec3),
+                ("n_energies", C.c_size_t), ("energies", c_double_p), ("weight", c_double_p),
+                ("amu", c_double_p), ("scatf", c_double_p),
+                ("i_refl", C.c_int64), ("d_travel", C.c_double)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "polycap_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.orc_within_pc_boundary.argtypes = [C.c_double, Vec3]
+        L.orc_within_pc_boundary.restype = C.c_int
+        L.orc_n_shells.argtypes = [C.c_int64]
+        L.orc_n_shells.restype = C.c_double
+        L.orc_open_area.argtypes = [C.POINTER(OpticS)]
+        L.orc_open_area.restype = C.c_double
+        L.orc_profile_new.argtypes = [C.c_int] + [C.c_double] * 7 + [C.c_int, c_double_p, c_double_p, c_double_p]
+        L.orc_profile_new.restype = C.c_int
+        L.orc_segment.argtypes = [Vec3, Vec3, C.c_double, C.c_double, Vec3, Vec3, Vec3, C.POINTER(Vec3), C.POINTER(Vec3)]
+        L.orc_segment.restype = C.c_int
+        L.orc_refl_polar.argtypes = [C.c_double] * 4 + [Vec3, C.POINTER(PhotonS), C.POINTER(Vec3)]
+        L.orc_refl_polar.restype = C.c_double
+        L.orc_reflect.argtypes = [C.POINTER(OpticS), C.POINTER(PhotonS), Vec3]
+        L.orc_reflect.restype = C.c_int
+        L.orc_trace.argtypes = [C.POINTER(OpticS), C.POINTER(C.c_int), C.POINTER(PhotonS), c_double_p, c_double_p]
+        L.orc_trace.restype = C.c_int
+        L.orc_launch_one.argtypes = [C.POINTER(OpticS), C.c_size_t, c_double_p, c_double_p, c_double_p,
+                                     c_double_p, c_double_p, c_double_p,
+                                     c_double_p, c_double_p, c_double_p, c_double_p, c_int64_p, c_double_p]
+        L.orc_launch_one.restype = C.c_int
+        L.orc_launch_batch.argtypes = [C.POINTER(OpticS), C.c_size_t, c_double_p, c_double_p, c_double_p, C.c_int64,
+                                       c_double_p, c_double_p, c_double_p,
+                                       C.POINTER(C.c_int), c_double_p, c_double_p, c_double_p, c_double_p,
+                                       c_int64_p, c_double_p, C.c_int]
+        L.orc_launch_batch.restype = None
+        L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_philox4x32_10.restype = None
+        L.orc_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.orc_uniform.restype = C.c_double
+        L.orc_sample_photon_flat.argtypes = [C.POINTER(OpticS), C.POINTER(SourceS), C.c_uint64, C.c_uint64, C.c_uint32, c_double_p]
+        L.orc_sample_photon_flat.restype = None
+        L.orc_transmission.argtypes = [C.POINTER(OpticS), C.POINTER(SourceS), C.c_size_t, c_double_p, c_double_p, c_double_p,
+                                       C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_uint32,
+                                       c_double_p, c_int64_p, c_double_p, c_double_p]
+        L.orc_transmission.restype = C.c_int
+        L.orc_efficiencies.argtypes = [C.c_size_t, c_double_p, c_int64_p, c_double_p]
+        L.orc_efficiencies.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def vec(t):
+    return Vec3(float(t[0]), float(t[1]), float(t[2]))
+
+
+class Optic:
+    """Profile arrays + glass parameters; keeps the numpy arrays alive behind the C struct."""
+
+    def __init__(self, z, cap, ext, sig_rough, n_cap, density):
+        self.z = np.ascontiguousarray(z, dtype=np.float64)
+        self.cap = np.ascontiguousarray(cap, dtype=np.float64)
+        self.ext = np.ascontiguousarray(ext, dtype=np.float64)
+        assert self.z.shape == self.cap.shape == self.ext.shape
+        self.nmax = self.z.shape[0] - 1
+        self.sig_rough, self.n_cap, self.density = float(sig_rough), int(n_cap), float(density)
+        self.s = OpticS(self.nmax, _dp(self.z), _dp(self.cap), _dp(self.ext), self.sig_rough, self.n_cap, self.density)
+
+    @classmethod
+    def from_shape(cls, ptype, length, rext_up, rext_down, rint_up, rint_down, f_up, f_down,
+                   sig_rough, n_cap, density, nmax=999):
+        z = np.zeros(nmax + 1)
+        cap = np.zeros(nmax + 1)
+        ext = np.zeros(nmax + 1)
+        rc = lib().orc_profile_new(ptype, length, rext_up, rext_down, rint_up, rint_down, f_up, f_down,
+                                   nmax, _dp(z), _dp(cap), _dp(ext))
+        if rc != 0:
+            raise ValueError("unsupported profile type %r" % (ptype,))
+        return cls(z, cap, ext, sig_rough, n_cap, density)
+
+    def open_area(self):
+        return lib().orc_open_area(C.byref(self.s))
+
+
+def make_source(d_source, src_x, src_y, sigx, sigy, shiftx, shifty, hor_pol):
+    return SourceS(d_source, src_x, src_y, sigx, sigy, shiftx, shifty, hor_pol)
+
+
+class Photon:
+    """Mutable photon for the per-function known-answer tests."""
+
+    def __init__(self, start, direction, elecv, energies=(10.0,), amu=(0.0,), scatf=(0.0,), weights=None):
+        self.energies = np.ascontiguousarray(energies, dtype=np.float64)
+        self.amu = np.ascontiguousarray(amu, dtype=np.float64)
+        self.scatf = np.ascontiguousarray(scatf, dtype=np.float64)
+        self.weight = np.ones_like(self.energies) if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        s = PhotonS()
+        s.start_coords = s.exit_coords = vec(start)
+        s.start_direction = s.exit_direction = vec(direction)
+        s.start_electric_vector = s.exit_electric_vector = vec(elecv)
+        s.n_energies = self.energies.shape[0]
+        s.energies, s.weight, s.amu, s.scatf = _dp(self.energies), _dp(self.weight), _dp(self.amu), _dp(self.scatf)
+        s.i_refl = 0
+        s.d_travel = 0.0
+        self.s = s
+
+
+def segment(cap0, cap1, rad0, rad1, phot0, phot1, pdir, last):
+    pc = vec(last)
+    sn = Vec3()
+    rc = lib().orc_segment(vec(cap0), vec(cap1), rad0, rad1, vec(phot0), vec(phot1), vec(pdir), C.byref(pc), C.byref(sn))
+    return rc, pc.tup(), sn.tup()
+
+
+def refl_polar(e, density, scatf, amu, surface_norm, photon):
+    ev = Vec3()
+    r = lib().orc_refl_polar(e, density, scatf, amu, vec(surface_norm), C.byref(photon.s), C.byref(ev))
+    return r, ev.tup()
+
+
+def reflect(optic, photon, surface_norm):
+    return lib().orc_reflect(C.byref(optic.s), C.byref(photon.s), vec(surface_norm))
+
+
+def trace(optic, ix, photon, cap_x, cap_y):
+    cx = np.ascontiguousarray(cap_x, dtype=np.float64)
+    cy = np.ascontiguousarray(cap_y, dtype=np.float64)
+    ixc = C.c_int(ix)
+    rc = lib().orc_trace(C.byref(optic.s), C.byref(ixc), C.byref(photon.s), _dp(cx), _dp(cy))
+    return rc, ixc.value
+
+
+def launch_one(optic, energies, amu, scatf, start, direction, elecv):
+    E = np.ascontiguousarray(energies, dtype=np.float64)
+    A = np.ascontiguousarray(amu, dtype=np.float64)
+    S = np.ascontiguousarray(scatf, dtype=np.float64)
+    w = np.zeros_like(E)
+    st, di, ev = (np.ascontiguousarray(v, dtype=np.float64) for v in (start, direction, elecv))
+    ec, ed, ee = np.zeros(3), np.zeros(3), np.zeros(3)
+    ir = C.c_int64(0)
+    dt = C.c_double(0)
+    rc = lib().orc_launch_one(C.byref(optic.s), E.shape[0], _dp(E), _dp(A), _dp(S), _dp(st), _dp(di), _dp(ev),
+                              _dp(w), _dp(ec), _dp(ed), _dp(ee), C.byref(ir), C.byref(dt))
+    return dict(rc=rc, weights=w, exit_coords=ec, exit_dir=ed, exit_elecv=ee, i_refl=ir.value, d_travel=dt.value)
+
+
+def launch_batch(optic, energies, amu, scatf, start, direction, elecv, n_threads=0):
+    E = np.ascontiguousarray(energies, dtype=np.float64)
+    A = np.ascontiguousarray(amu, dtype=np.float64)
+    S = np.ascontiguousarray(scatf, dtype=np.float64)
+    st = np.ascontiguousarray(start, dtype=np.float64).reshape(-1, 3)
+    di = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+    ev = np.ascontiguousarray(elecv, dtype=np.float64).reshape(-1, 3)
+    n = st.shape[0]
+    rc = np.zeros(n, dtype=np.int32)
+    w = np.zeros((n, E.shape[0]))
+    ec, ed, ee = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 3))
+    ir = np.zeros(n, dtype=np.int64)
+    dt = np.zeros(n)
+    lib().orc_launch_batch(C.byref(optic.s), E.shape[0], _dp(E), _dp(A), _dp(S), n, _dp(st), _dp(di), _dp(ev),
+                           rc.ctypes.data_as(C.POINTER(C.c_int)), _dp(w), _dp(ec), _dp(ed), _dp(ee),
+                           ir.ctypes.data_as(c_int64_p), _dp(dt), n_threads)
+    return dict(rc=rc, weights=w, exit_coords=ec, exit_dir=ed, exit_elecv=ee, i_refl=ir, d_travel=dt)
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return tuple(int(v) for v in o)
+
+
+def uniform(seed, slot, attempt, d):
+    return lib().orc_uniform(seed, slot, attempt, d)
+
+
+def sample_photons(optic, source, seed, slots, attempt=0):
+    """(n,12) array: start(3), dir(3), elecv(3), src_start(3) of attempt `attempt` of each slot."""
+    slots = np.asarray(slots, dtype=np.int64)
+    out = np.zeros((slots.shape[0], 12))
+    buf = np.zeros(12)
+    for i, s in enumerate(slots):
+        lib().orc_sample_photon_flat(C.byref(optic.s), C.byref(source), seed, int(s), attempt, _dp(buf))
+        out[i] = buf
+    return out
+
+
+IMG_FIELDS = ("src_start_x", "src_start_y", "pc_start_x", "pc_start_y", "pc_start_dir_x", "pc_start_dir_y",
+              "pc_start_elecv_x", "pc_start_elecv_y", "pc_exit_x", "pc_exit_y", "pc_exit_z",
+              "pc_exit_dir_x", "pc_exit_dir_y", "pc_exit_elecv_x", "pc_exit_elecv_y", "nrefl", "dtravel")
+
+
+def transmission(optic, source, energies, amu, scatf, seed, slot0, n_slots, n_threads=0,
+                 max_attempts=1 << 20, images=False):
+    E = np.ascontiguousarray(energies, dtype=np.float64)
+    A = np.ascontiguousarray(amu, dtype=np.float64)
+    S = np.ascontiguousarray(scatf, dtype=np.float64)
+    sw = np.zeros_like(E)
+    cnt = np.zeros(4, dtype=np.int64)
+    img = np.zeros((n_slots, 17)) if images else None
+    ew = np.zeros((n_slots, E.shape[0])) if images else None
+    rc = lib().orc_transmission(C.byref(optic.s), C.byref(source), E.shape[0], _dp(E), _dp(A), _dp(S),
+                                seed, slot0, n_slots, n_threads, max_attempts,
+                                _dp(sw), cnt.ctypes.data_as(c_int64_p),
+                                _dp(img) if images else None, _dp(ew) if images else None)
+    eff = np.zeros_like(E)
+    if cnt[0] + cnt[1] + cnt[2] > 0:
+        lib().orc_efficiencies(E.shape[0], _dp(sw), cnt.ctypes.data_as(c_int64_p), _dp(eff))
+    return dict(rc=rc, sum_weights=sw, counters=cnt, efficiencies=eff, images=img, exit_weights=ew,
+                i_exit=int(cnt[0]), not_entered=int(cnt[1]), not_transmitted=int(cnt[2]), sum_irefl=int(cnt[3]),
+                i_start=int(cnt[0] + cnt[1] + cnt[2]))
