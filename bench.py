@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the photon trace path (BASELINE.json: xos1.inp, 10 keV).
+
+One "step" = one pass of the hot path over one batch: polycap_source_get_transmission_efficiencies for
+--photons exit-photon slots per GPU (default 1e7 = BASELINE config C2) on the xos1 optic at 10 keV, image planes
+kept in HBM, followed by the one RCCL all-reduce of the per-energy histogram.  Inputs (profile tables, optical
+constants, source parameters) are resident in HBM before the timed region; outputs stay in HBM.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+value = started photons per second (i_start / wall; the unit of simulation work and the denominator of the
+efficiency), whole job, max-over-ranks wall time; exit photons/s is printed next to it.
+Weak scaling: every rank traces --photons slots.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_EXIT_PHOTON = 17 * 8   # 17 image planes of 8 B; + 8 B per energy for exit_coord_weights
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--photons", type=int, default=10_000_000, help="exit-photon slots per GPU per step")
+    ap.add_argument("--seed", type=int, default=20000)
+    ap.add_argument("--no-images", action="store_true", help="histogram-only mode (no per-photon planes)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=400_000, help="exit-photon slots of the CPU baseline sample")
+    ap.add_argument("--opt", action="append", default=[], help="kernel option name=value (event_threshold, blocks_per_cu, ...)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import polycap_amd
+    from polycap_amd import distributed as pcd
+
+    if polycap_amd.device_count() < 1:
+        sys.exit("bench.py: no HIP device (the trace path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    deck = os.path.join(ROOT, "tests", "golden", "example", "xos1.inp")
+    prob = polycap_amd.problem_from_inp(deck, energies=[10.0])
+    ne = prob.n_energies
+    keep_images = not args.no_images
+    ctx = polycap_amd.TraceContext(prob, local_rank)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    n_local = args.photons
+    slot0 = rank * n_local           # weak scaling: rank r owns slots [r*n, (r+1)*n)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(k):
+        ctx.run(args.seed + k, slot0, n_local, keep_images=keep_images)
+        ms = ctx.wait()
+        t = ctx.totals()
+        vec = pcd.pack_totals(t["counters"], t["sumw_fixed"])
+        vec = pcd.allreduce_totals(vec, dev)
+        return ms, vec
+
+    for k in range(args.warmup):
+        step(-1 - k)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms, started, exited = [], 0, 0
+    last = None
+    for k in range(args.steps):
+        ms, vec = step(k)
+        kernel_ms.append(ms)
+        counters, sums, _ = pcd.unpack_totals(vec)
+        started += int(counters[0] + counters[1] + counters[2])
+        exited += int(counters[0])
+        last = (counters, sums)
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+
+    if rank == 0:
+        counters, sums = last
+        eff = pcd.efficiencies_from_totals(counters, sums)
+        avg_ms = float(np.mean(kernel_ms))
+        per_launch_exit = n_local
+        alg_bytes = per_launch_exit * (BYTES_PER_EXIT_PHOTON + 8 * ne) if keep_images else 8.0 * (ne + 6)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "photons/s (started photons, whole job), xos1 10 keV",
+            "value": started / wall,
+            "unit": "photons/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (Philox-sampled parallel beam on the xos1 profile tables; O/Si glass constants pinned at 10 keV)",
+            "config": {"workload": "example/xos1.inp, 10 keV single energy, %d exit photons per GPU per step%s" %
+                                   (n_local, "" if keep_images else ", histogram only"),
+                       "exit_photons_per_gpu": n_local, "n_energies": ne, "images": keep_images,
+                       "parallelism": "slots sharded over %d GPU(s), one RCCL all-reduce of the histogram per step" % world},
+            "exit_photons_per_s": exited / wall,
+            "efficiency_10keV": float(eff[0]),
+            "avg_reflections": float(counters[3]) / max(1, int(counters[0])),
+            "started_per_exit": started / max(1, exited),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pc_trace_kernel<1,0>", "kernel_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "fp64-VALU/divergence-bound by construction (SURVEY 8d): 144 B per exit photon"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(prob, args, ctx)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(prob, args, ctx):
+    """The CPU oracle (plain-C restatement of the reference algorithm, OpenMP over slots) timed on this host on a
+    bounded sample of the same workload, plus the efficiency delta GPU vs CPU on exactly those slots."""
+    from oracle import pyoracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    n = args.cpu_sample
+    optic = O.Optic(prob.z, prob.cap, prob.ext, prob.sig_rough, prob.n_cap, prob.density)
+    src = O.make_source(*prob.source)
+    O.transmission(optic, src, prob.energies, prob.amu, prob.scatf, args.seed, 0, 2000, n_threads=cores)  # warm up
+    t0 = time.perf_counter()
+    o = O.transmission(optic, src, prob.energies, prob.amu, prob.scatf, args.seed, 0, n, n_threads=cores)
+    dt = time.perf_counter() - t0
+    g = ctx.transmission(args.seed, 0, n, keep_images=False)
+    return {"value": o["i_start"] / dt, "unit": "photons/s", "cores": cores, "kind": "port",
+            "sample": "oracle (C restatement of the reference, literal segment march, OpenMP) on slots [0,%d) of the same "
+                      "xos1 10 keV workload, %.1f s" % (n, dt),
+            "exit_photons_per_s": o["i_exit"] / dt,
+            "efficiency_cpu": float(o["efficiencies"][0]), "efficiency_gpu_same_slots": float(g["efficiencies"][0]),
+            "eff_rel_delta": abs(float(g["efficiencies"][0]) - float(o["efficiencies"][0])) / float(o["efficiencies"][0]),
+            "eff_delta_note": "identical seeds; the trace is chaotic (1-ulp self-noise ~0.25/sqrt(N)), so the delta "
+                              "falls as 1/sqrt(N): see tests/test_chaos_floor.py"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+/*
+ * polycap-hip.h -- the thin C-ABI between libpolycap's host C code and its HIP (gfx950) kernels.
+ *
+ * Plain C: pointers, sizes and ints only; nothing HIP- or torch-typed crosses this boundary, so the
+ * same entry points can be bound from C, ctypes, Cython or cgo.  The reference has no such layer (it
+ * has no GPU code); each entry point names the reference function whose work it takes over.
+ *
+ * All functions return 0 on success or a negative pc_hip_status; pc_hip_last_error() gives the text.
+ * There is no CPU fallback behind any of them: without a usable HIP device they fail with
+ * PC_HIP_ERR_NO_DEVICE.
+ */
+#ifndef POLYCAP_HIP_H
+#define POLYCAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef POLYCAP_EXTERN
+#define POLYCAP_EXTERN __attribute__((visibility("default"))) extern
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+	PC_HIP_OK = 0,
+	PC_HIP_ERR_NO_DEVICE = -1,   /* no HIP device / runtime not usable */
+	PC_HIP_ERR_INVALID = -2,     /* bad argument or unsupported problem shape */
+	PC_HIP_ERR_RUNTIME = -3,     /* a HIP API call or a kernel failed */
+	PC_HIP_ERR_MEMORY = -4,      /* host or device allocation failed */
+	PC_HIP_ERR_ATTEMPTS = -5     /* some slot used max_attempts launches without a transmitted photon */
+} pc_hip_status;
+
+/* One simulation problem: optic geometry + glass + energy tables + X-ray source.
+ * Plain-array mirror of the reference's _polycap_profile / _polycap_description / _polycap_source
+ * (src/polycap-private.h:88-122).  amu[]/scatf[] are what polycap_photon_scatf()
+ * (src/polycap-photon.c:22-94) computes per launch; here they are computed once by the host.
+ * Everything is copied at pc_hip_ctx_create(); the caller keeps ownership. */
+typedef struct {
+	int32_t nmax;                 /* profile arrays hold nmax+1 points, z strictly increasing, z[0] >= 0 */
+	const double *z, *cap, *ext;
+	double sig_rough;
+	int64_t n_cap;
+	double density;
+	size_t n_energies;
+	const double *energies, *amu, *scatf;
+	double d_source, src_x, src_y, src_sigx, src_sigy, src_shiftx, src_shifty, hor_pol;
+} pc_hip_problem;
+
+/* Host destination planes for per-exit-photon "images": the SoA of struct _polycap_images
+ * (src/polycap-private.h:156-181), leak fields excluded.  Any pointer may be NULL to skip that plane. */
+typedef struct {
+	double *src_start_coords[2];
+	double *pc_start_coords[2];
+	double *pc_start_dir[2];
+	double *pc_start_elecv[2];
+	double *pc_exit_coords[3];
+	double *pc_exit_dir[2];
+	double *pc_exit_elecv[2];
+	int64_t *pc_exit_nrefl;
+	double *pc_exit_dtravel;
+	double *exit_coord_weights;   /* [count * n_energies], row-major by photon */
+} pc_hip_images;
+
+typedef struct pc_hip_ctx pc_hip_ctx;
+
+POLYCAP_EXTERN int pc_hip_device_count(void);
+POLYCAP_EXTERN const char *pc_hip_last_error(void);
+
+/* Uploads the problem to `device` (tables resident in HBM, staged into LDS by every workgroup). */
+POLYCAP_EXTERN int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ctx);
+POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
+
+/* Tuning / test switches: "literal_march" (1 = visit every segment with the reference's full quadratic,
+ * 0 = certified skipping, default), "event_threshold" (lanes), "waves_per_cu", "block_size". */
+POLYCAP_EXTERN int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value);
+
+/* polycap_photon_launch (src/polycap-photon.c:390-955, leak_calc=false) for n explicit photons.
+ * Inputs [3*n] xyz-interleaved host arrays; outputs rc[n] in {1,0,2,-2,-1}, weights[n*n_energies],
+ * exit_*[3*n] (state at the last interaction, as polycap_photon_get_exit_*), i_refl[n], d_travel[n]. */
+POLYCAP_EXTERN int pc_hip_launch_photons(pc_hip_ctx *ctx, int64_t n,
+	const double *start_coords, const double *start_dir, const double *start_elecv,
+	int32_t *rc, double *weights, double *exit_coords, double *exit_dir, double *exit_elecv,
+	int64_t *i_refl, double *d_travel);
+
+/* polycap_source_get_photon (src/polycap-source.c:23-144) evaluated on the device for the given
+ * (slot, attempt) pairs of the Philox stream `seed`; out[12*n] = start(3), dir(3), elecv(3), src_start(3). */
+POLYCAP_EXTERN int pc_hip_sample_photons(pc_hip_ctx *ctx, uint64_t seed, int64_t n,
+	const int64_t *slots, const uint32_t *attempts, double *out);
+
+/* polycap_source_get_transmission_efficiencies (src/polycap-source.c:448-1087, leak_calc=false) for the
+ * exit-photon slots [slot0, slot0+n_slots): enqueue on the context's stream; results stay in HBM.
+ * keep_images=0 is the histogram-only mode (no per-photon planes are allocated or written). */
+POLYCAP_EXTERN int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64_t n_slots,
+	uint32_t max_attempts, int keep_images);
+/* Waits for the stream; *kernel_ms (optional) = duration of the trace kernel between two HIP events
+ * recorded on that stream. */
+POLYCAP_EXTERN int pc_hip_transmission_wait(pc_hip_ctx *ctx, float *kernel_ms);
+/* Totals of the last run: sum_weights[n_energies]; counters = {iexit, not_entered, not_transmitted,
+ * sum_irefl, failed_slots, launches}; sumw_fixed (optional) [2*n_energies] = exact 128-bit fixed-point sums
+ * (lo, hi) in units of 2^-62, which add exactly across devices. */
+POLYCAP_EXTERN int pc_hip_transmission_totals(pc_hip_ctx *ctx, double *sum_weights, int64_t counters[6], uint64_t *sumw_fixed);
+/* Copies image planes of slots [first, first+count) (relative to slot0 of the last run) to the host. */
+POLYCAP_EXTERN int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const pc_hip_images *dst);
+
+/* efficiency formula of src/polycap-source.c:1066-1076 from (summed) totals */
+POLYCAP_EXTERN void pc_hip_efficiencies(size_t n_energies, const double *sum_weights, const int64_t counters[6], double *efficiencies);
+/* exact fixed-point (lo,hi) pair -> double */
+POLYCAP_EXTERN double pc_hip_fixed_to_double(uint64_t lo, uint64_t hi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,655 @@
+/*
+ * pc_device.h -- per-photon device logic of the MI355X trace path (fp64).
+ *
+ * One lane owns one photon.  The logic is written as small state-transition functions so the
+ * kernels (pc_kernels.hip) can schedule the three phases of a photon's life wave-wide:
+ *   MARCH  : walk profile nodes with a 6-FMA "still strictly inside the capillary" certificate
+ *   EVENT  : the reference's full segment quadratic + wall hit + Fresnel reflection
+ *   NEW    : source sampling (Philox4x32-10) + entrance tests
+ *
+ * Reference functions restated here (reference v1.2, file:line):
+ *   polycap_source_get_photon          src/polycap-source.c:23-144      -> pc_sample_photon
+ *   polycap_photon_launch              src/polycap-photon.c:390-955     -> pc_launch_init + kernel loop
+ *   polycap_capil_trace                src/polycap-capil.c:1197-1361    -> pc_march_ok / pc_event
+ *   polycap_capil_segment              src/polycap-capil.c:52-255       -> pc_segment
+ *   polycap_capil_reflect              src/polycap-capil.c:565-655      -> pc_reflect
+ *   polycap_refl_polar                 src/polycap-capil.c:444-563      -> pc_reflect (energy loop)
+ *   polycap_photon_within_pc_boundary  src/polycap-photon.c:139-169     -> pc_outside_hex
+ *
+ * The functions are PC_HD so that tests can also compile this header as host code and drive it
+ * photon by photon (tests/emul/, never part of libpolycap).
+ */
+#ifndef PC_DEVICE_H
+#define PC_DEVICE_H
+
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define PC_HD __host__ __device__ __forceinline__
+#else
+#define PC_HD inline
+#endif
+
+#define PC_COSPI_6 0.86602540378443864676
+#define PC_PI 3.14159265358979323846
+
+/* photon life-cycle states (per lane) */
+enum { PC_ST_IDLE = 0, PC_ST_NEW = 1, PC_ST_MARCH = 2, PC_ST_EVENT = 3, PC_ST_DONE = 4 };
+
+/* per-energy constants, precomputed on the host from (E, density, scatf, amu):
+ * n = (1-alfa) + i*beta  (src/polycap-capil.c:497-499); ninv2 = (1/n)^2; rough_c = 1.01358*E*sig_rough */
+struct pc_energy_const {
+	double n_re, n_im;
+	double ninv2_re, ninv2_im;
+	double rough_c;
+	double valid;   /* 0 -> polycap_refl_polar would reject its arguments (returns -1) */
+};
+
+struct pc_params {
+	int nmax;
+	int mono;           /* n_shells == 0 */
+	int n_energies;
+	int literal;        /* 1: no certificate, every segment takes the full quadratic */
+	int uniform_illum;  /* src_sigx < 0 || src_sigy < 0 */
+	int generic_src;    /* src_x != src_y: elliptical source, libm sampling path */
+	double n_shells;
+	double hexscale;    /* 2*cos(pi/6)*(n_shells+1) */
+	double adj;         /* certificate margin: see pc_march_ok */
+	double bnd_thresh;  /* max_i cap[i]/ext[i] (+slack): capillaries closer than this to the hexagon edge are "boundary" */
+	double z_end, ext_end;
+	double d_source, src_x, src_y, src_sigx, src_sigy, src_shiftx, src_shifty, frac_hor_pol;
+	double cap0, ext0;
+};
+
+/* profile tables.  z/cap/zh/cap2 are the MARCH tables (LDS on the device), ext is only read on events. */
+struct pc_tables {
+	const double *z;
+	const double *cap;
+	const double *zh;    /* ext[i] / hexscale: capillary axis = (kx, ky) * zh[i]  (src/polycap-photon.c:624-627) */
+	const double *cap2;  /* cap[i]^2 */
+	const double *hexd;  /* sqrt(ext^2 - (ext/2)^2): centre-to-edge distance of the outer hexagon at node i */
+	const double *ext;
+};
+
+template <int NE>
+struct pc_photon {
+	double Px, Py, Pz;      /* exit_coords: last interaction point */
+	double dx, dy, dz;      /* exit_direction (unit) */
+	double ex, ey, ez;      /* exit_electric_vector */
+	double kx, ky;          /* capillary axis scale factors */
+	double sx, sy, ox, oy;  /* ray of the current trace call: p(z) = o + s*z */
+	double C0;              /* |p - axis|^2 - cap^2 at node i (certificate chain) */
+	double dtravel;
+	double w[NE > 0 ? NE : 1]; /* NE > 0: one weight per energy in registers */
+	double *wmem;              /* NE == 0: n_energies weights in memory at wmem[e*wstride] */
+	long wstride;
+	int i;                  /* segment [z_i, z_i+1] to be visited next */
+	int irefl;
+	int ntrace;             /* completed polycap_capil_trace calls that returned 1 */
+	int first;              /* 1: segment i is the first of a trace call (last hit lies inside it) */
+	int bnd;                /* 1: boundary capillary, hexagon tests are done at every node */
+	int rc;                 /* final polycap_photon_launch return code once DONE */
+};
+
+/* ------------------------------------------------------------------ small helpers */
+
+PC_HD void pc_norm3(double &x, double &y, double &z)
+{
+	double inv = 1.0 / sqrt(x*x + y*y + z*z);
+	x *= inv; y *= inv; z *= inv;
+}
+
+/* hexagon test of polycap_photon_within_pc_boundary given the centre-to-edge distance d;
+ * returns 1 when OUTSIDE (NaN coordinates compare false -> inside, as in the reference) */
+PC_HD int pc_outside_hexd(double d, double x, double y)
+{
+	double dp1 = fabs(y);
+	double dp2 = fabs(PC_COSPI_6*x + 0.5*y);
+	double dp3 = fabs(PC_COSPI_6*x - 0.5*y);
+	return (dp1 > d || dp2 > d || dp3 > d) ? 1 : 0;
+}
+
+/* same from the circum-radius (radius <= 0 -> the reference returns -1, which its callers treat like "inside") */
+PC_HD int pc_outside_hex(double radius, double x, double y)
+{
+	if (radius <= 0.) return 0;
+	double half = radius * 0.5;
+	return pc_outside_hexd(sqrt(radius*radius - half*half), x, y);
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10 */
+
+PC_HD void pc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+	for (int r = 0; r < 10; r++) {
+		uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+		uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+		uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+		uint32_t n1 = (uint32_t)p1;
+		uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+		uint32_t n3 = (uint32_t)p0;
+		c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+		k0 += 0x9E3779B9u;
+		k1 += 0xBB67AE85u;
+	}
+	out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* stream (seed, slot, attempt): uniform #d, two 53-bit uniforms per Philox block */
+struct pc_rng {
+	uint64_t seed, slot;
+	uint32_t attempt, d;
+	uint32_t buf[4];
+};
+
+PC_HD void pc_rng_init(pc_rng &g, uint64_t seed, uint64_t slot, uint32_t attempt)
+{
+	g.seed = seed; g.slot = slot; g.attempt = attempt; g.d = 0;
+}
+
+PC_HD double pc_rng_uniform(pc_rng &g)
+{
+	uint32_t d = g.d++;
+	if ((d & 1u) == 0u)
+		pc_philox4x32_10((uint32_t)g.slot, (uint32_t)(g.slot >> 32), g.attempt, d >> 1,
+		                 (uint32_t)g.seed, (uint32_t)(g.seed >> 32), g.buf);
+	uint64_t w = (d & 1u) ? (((uint64_t)g.buf[3] << 32) | g.buf[2]) : (((uint64_t)g.buf[1] << 32) | g.buf[0]);
+	return (double)(w >> 11) * (1.0/9007199254740992.0);
+}
+
+/* ------------------------------------------------------------------ source sampling */
+
+struct pc_start {
+	double x, y, z;        /* start_coords */
+	double dx, dy, dz;     /* start_direction (unit) */
+	double ex, ey, ez;     /* start_electric_vector (unit, perpendicular to the direction) */
+	double srcx, srcy;     /* src_start_coords */
+};
+
+/* sin and cos on [0, pi/2] without the generic argument reduction (fdlibm-style kernels on [0, pi/4],
+ * Cody-Waite pi/2 = hi + lo); < 1 ulp.  Keeps libm's large-argument paths out of the trace kernel. */
+PC_HD void pc_sincos_quadrant(double x, double &sn, double &cs)
+{
+	const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
+	const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+	             S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+	const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+	             C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+	const int swap = x > 0.78539816339744830962;
+	const double y = swap ? ((pio2_hi - x) + pio2_lo) : x;
+	const double z = y*y;
+	const double ps = S1 + z*(S2 + z*(S3 + z*(S4 + z*(S5 + z*S6))));
+	const double pcs = C1 + z*(C2 + z*(C3 + z*(C4 + z*(C5 + z*C6))));
+	const double s = y + y*z*ps;
+	const double hz = 0.5*z;
+	const double c = (1.0 - hz) + z*z*pcs;
+	sn = swap ? c : s;
+	cs = swap ? s : c;
+}
+
+/* src/polycap-source.c:23-144.  GENERIC=false is the circular source (src_x == src_y), where
+ * atan(src_y/src_x*tan(x)) == x up to rounding; GENERIC=true evaluates the elliptical formula with libm. */
+template <bool GENERIC>
+PC_HD void pc_sample_photon(const pc_params &Pm, uint64_t seed, uint64_t slot, uint32_t attempt, pc_start &s)
+{
+	pc_rng g;
+	pc_rng_init(g, seed, slot, attempt);
+	double r = pc_rng_uniform(g);
+	double cphi, sphi;
+	if (GENERIC) {
+		double phi = atan(Pm.src_y/Pm.src_x * tan(2.0*PC_PI*r/4.));
+		r = pc_rng_uniform(g);
+		if ((r >= 0.25) && (r < 0.5)) phi = PC_PI - phi;
+		if ((r >= 0.5) && (r < 0.75)) phi = PC_PI + phi;
+		if (r >= 0.75) phi = -1.0 * phi;
+		cphi = cos(phi); sphi = sin(phi);
+	} else {
+		double phi = 2.0*PC_PI*r/4.;
+		pc_sincos_quadrant(phi, sphi, cphi);
+		r = pc_rng_uniform(g);
+		/* phi -> pi-phi, pi+phi, -phi : :57-62 */
+		if ((r >= 0.25) && (r < 0.75)) cphi = -cphi;
+		if (r >= 0.5) sphi = -sphi;
+	}
+	double max_rad = Pm.src_x*Pm.src_y / sqrt((Pm.src_y*cphi)*(Pm.src_y*cphi) + (Pm.src_x*sphi)*(Pm.src_x*sphi));
+	r = pc_rng_uniform(g);
+	double sr = sqrt(r);
+	s.srcx = sr * max_rad * cphi + Pm.src_shiftx;
+	s.srcy = sr * max_rad * sphi + Pm.src_shifty;
+	if (Pm.uniform_illum) {
+		/* :74-96 */
+		if (Pm.mono) {
+			r = pc_rng_uniform(g);
+			s.x = (2.*r-1.) * Pm.cap0;
+			r = pc_rng_uniform(g);
+			s.y = (2.*r-1.) * Pm.cap0;
+		} else {
+			int outside;
+			do {
+				r = pc_rng_uniform(g);
+				s.x = (2.*r-1.) * Pm.ext0;
+				r = pc_rng_uniform(g);
+				s.y = (2.*r-1.) * Pm.ext0;
+				outside = pc_outside_hex(Pm.ext0, s.x, s.y);
+			} while (outside && g.d < 4096u); /* the reference loops unbounded; acceptance is ~65 % per try */
+		}
+		s.dx = s.x - s.srcx;
+		s.dy = s.y - s.srcy;
+		s.dz = Pm.d_source;
+	} else {
+		/* :97-108 */
+		r = pc_rng_uniform(g);
+		s.dx = Pm.src_sigx * (1.-2.*fabs(r));
+		r = pc_rng_uniform(g);
+		s.dy = Pm.src_sigy * (1.-2.*fabs(r));
+		s.dz = 1.;
+		s.x = s.srcx + s.dx * Pm.d_source / s.dz;
+		s.y = s.srcy + s.dy * Pm.d_source / s.dz;
+	}
+	s.z = 0.;
+	pc_norm3(s.dx, s.dy, s.dz);
+	/* :114-137 polarisation */
+	r = pc_rng_uniform(g);
+	double e0x, e0y;
+	if (fabs(r) <= Pm.frac_hor_pol) { e0x = 1.; e0y = 0.; } else { e0x = 0.; e0y = 1.; }
+	double cosalpha = e0x*s.dx + e0y*s.dy;
+	/* c_ae = 1/sin(acos(c)), c_be = -c_ae*c */
+	double c_ae = 1.0 / sqrt(1.0 - cosalpha*cosalpha);
+	double c_be = -1.*c_ae*cosalpha;
+	s.ex = e0x * c_ae + s.dx * c_be;
+	s.ey = e0y * c_ae + s.dy * c_be;
+	s.ez = s.dz * c_be;
+	pc_norm3(s.ex, s.ey, s.ez);
+}
+
+/* ------------------------------------------------------------------ launch entrance tests */
+
+PC_HD int pc_last_node_le(const pc_tables &T, int upto, double zval)
+{
+	int idx = 0;
+	for (int j = 0; j < upto; j++)
+		if (T.z[j] <= zval) idx = j;
+	return idx;
+}
+
+/* begin a polycap_capil_trace call at segment ph.i: src/polycap-capil.c:1236-1243 */
+template <int NE>
+PC_HD void pc_trace_begin(pc_photon<NE> &ph)
+{
+	double idz = 1.0 / ph.dz;
+	ph.sx = ph.dx * idz;
+	ph.sy = ph.dy * idz;
+	ph.ox = ph.Px - ph.sx * ph.Pz;
+	ph.oy = ph.Py - ph.sy * ph.Pz;
+	ph.first = 1;
+}
+
+/* src/polycap-photon.c:458-645 + 888-906.  Returns PC_ST_MARCH when the photon entered a capillary,
+ * else PC_ST_DONE with ph.rc in {2, -2}. */
+template <int NE>
+PC_HD int pc_launch_init(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph,
+                         double x, double y, double z, double dx, double dy, double dz,
+                         double ex, double ey, double ez)
+{
+	const int nmax = Pm.nmax;
+	pc_norm3(dx, dy, dz);
+	ph.Px = x; ph.Py = y; ph.Pz = z;
+	ph.dx = dx; ph.dy = dy; ph.dz = dz;
+	ph.ex = ex; ph.ey = ey; ph.ez = ez;
+	ph.irefl = 0; ph.ntrace = 0; ph.dtravel = 0.; ph.rc = 0; ph.C0 = 0.; ph.bnd = 0;
+	{
+		const int ne = (NE > 0) ? NE : Pm.n_energies;
+		for (int e = 0; e < ne; e++) {
+			if (NE > 0) ph.w[e] = 1.; else ph.wmem[e*ph.wstride] = 1.;
+		}
+	}
+
+	/* :507-512 */
+	int z_id = (z > 0) ? pc_last_node_le(T, nmax, z) : 0;
+	double cur_ext = ((T.ext[z_id] - T.ext[z_id+1]) / (T.z[z_id] - T.z[z_id+1])) * (z - T.z[z_id]) + T.ext[z_id];
+	double q_i = 0., r_i = 0.;
+	if (Pm.mono) {
+		if (sqrt(x*x + y*y) > cur_ext) { ph.rc = -2; return PC_ST_DONE; }
+	} else {
+		/* :540-552 axial hex coordinates + cube rounding */
+		double zz = cur_ext / Pm.hexscale;
+		r_i = y * (2./3) / zz;
+		q_i = (x/(2.*PC_COSPI_6) - y/3) / zz;
+		double rq = round(q_i), rr = round(r_i), rs = round(-1.*q_i - r_i);
+		double dq = fabs(q_i - rq), dr = fabs(r_i - rr), ds = fabs(-1.*q_i - r_i - rs);
+		if (dq > dr && dq > ds) {
+			q_i = -1.*rr - rs;
+			r_i = rr;
+		} else if (dr > ds) {
+			r_i = -1.*rq - rs;
+			q_i = rq;
+		} else {
+			q_i = rq;
+			r_i = rr;
+		}
+		if (pc_outside_hex(cur_ext, x, y)) { ph.rc = -2; return PC_ST_DONE; }
+	}
+	/* :624-627 */
+	ph.ky = r_i * (3./2);
+	ph.kx = (2.*q_i + r_i) * PC_COSPI_6;
+	ph.i = (z > 0) ? pc_last_node_le(T, nmax + 1, z) : 0;
+	/* :629-645 */
+	double cur_rad, cur_cx, cur_cy;
+	if (z > 0) {
+		double dzseg = T.z[z_id+1] - T.z[z_id];
+		double cx0 = ph.kx*T.zh[z_id], cx1 = ph.kx*T.zh[z_id+1];
+		double cy0 = ph.ky*T.zh[z_id], cy1 = ph.ky*T.zh[z_id+1];
+		cur_rad = ((T.cap[z_id+1] - T.cap[z_id])/dzseg) * (z - T.z[z_id]) + T.cap[z_id];
+		cur_cx = ((cx1 - cx0)/dzseg) * (z - T.z[z_id]) + cx0;
+		cur_cy = ((cy1 - cy0)/dzseg) * (z - T.z[z_id]) + cy0;
+	} else {
+		cur_rad = T.cap[0];
+		cur_cx = ph.kx*T.zh[0];
+		cur_cy = ph.ky*T.zh[0];
+	}
+	double d_ph_capcen = sqrt((x-cur_cx)*(x-cur_cx) + (y-cur_cy)*(y-cur_cy));
+	if (d_ph_capcen > cur_rad) { ph.rc = 2; return PC_ST_DONE; }
+
+	/* boundary capillary?  The capillary circle at node i stays inside the outer hexagon iff
+	 *   hexd_i - max_j|n_j.axis_i| - cap_i > 0,  hexd_i = ext_i*sqrt(3)/2,  axis_i = (kx,ky)*ext_i/hexscale
+	 * <=> sqrt(3)/2 - M/hexscale > cap_i/ext_i  with  M = max_j |n_j.(kx,ky)|.  bnd_thresh = max_i cap_i/ext_i (+slack). */
+	if (!Pm.mono) {
+		double m1 = fabs(ph.ky);
+		double m2 = fabs(PC_COSPI_6*ph.kx + 0.5*ph.ky);
+		double m3 = fabs(PC_COSPI_6*ph.kx - 0.5*ph.ky);
+		double M = fmax(m1, fmax(m2, m3));
+		ph.bnd = (PC_COSPI_6 - M/Pm.hexscale > Pm.bnd_thresh) ? 0 : 1;
+	} else {
+		ph.bnd = 1; /* mono-capillary: the reference's hexagon tests still run (against ext); keep them literal */
+	}
+	pc_trace_begin(ph);
+	return PC_ST_MARCH;
+}
+
+/* ------------------------------------------------------------------ MARCH certificate
+ *
+ * Within segment i both the ray-to-axis offset q(u) and the capillary radius R(u) are linear in
+ * u=(z-z_i)/(z_i+1-z_i), so g(u) = |q(u)|^2 - R(u)^2 = A u^2 + B u + C with A = |dq|^2 - dR^2 >= -dR^2.
+ * A quadratic deviates from its chord by at most |A|/4 on [0,1], hence
+ *     g(u) <= max(g(0), g(1)) + dR^2/4   for all u in [0,1].
+ * If g(0) and g(1) are both below -(dRmax^2/4 + m) the photon is strictly inside the capillary over the
+ * whole segment: the reference's quadratic (src/polycap-capil.c:119-157) has no root in the segment
+ * (it returns -2/-3/-4/-5), the capillary lies inside the outer hexagon (non-boundary capillaries), so its
+ * hexagon tests (src/polycap-capil.c:1263,1301) pass as well: the visit is a certain "miss" and is skipped.
+ * adj = dRmax^2/4 + m with m ~ 1e6 x the rounding error of g.  Anything else goes to pc_event().
+ * Cost: 6 FMA + 3 LDS reads per node.
+ */
+template <int NE>
+PC_HD int pc_march_ok(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph)
+{
+	int i1 = ph.i + 1;
+	double z1 = T.z[i1], zh1 = T.zh[i1], c2 = T.cap2[i1];
+	double qx = fma(-ph.kx, zh1, fma(ph.sx, z1, ph.ox));
+	double qy = fma(-ph.ky, zh1, fma(ph.sy, z1, ph.oy));
+	double C1 = fma(qx, qx, fma(qy, qy, -c2));
+	int ok = (ph.C0 < -Pm.adj) & (C1 < -Pm.adj);
+	if (ph.bnd) {
+		/* boundary capillary (or mono-capillary): the hexagon tests of the visit are not implied, do them:
+		 * axis at both nodes (src/polycap-capil.c:1263) and the ray at z_i (:1296-1308) */
+		int i0 = ph.i;
+		double z0 = T.z[i0], zh0 = T.zh[i0], h0 = T.hexd[i0], h1 = T.hexd[i1];
+		double px = fma(ph.sx, z0, ph.ox), py = fma(ph.sy, z0, ph.oy);
+		ok &= !pc_outside_hexd(h0, ph.kx*zh0, ph.ky*zh0);
+		ok &= !pc_outside_hexd(h1, ph.kx*zh1, ph.ky*zh1);
+		ok &= !pc_outside_hexd(h0, px, py);
+	}
+	if (ok) { ph.C0 = C1; ph.i = i1; }
+	return ok;
+}
+
+/* certificate value at node idx for the current ray */
+template <int NE>
+PC_HD double pc_node_C(const pc_tables &T, const pc_photon<NE> &ph, int idx)
+{
+	double z1 = T.z[idx], zh1 = T.zh[idx], c2 = T.cap2[idx];
+	double qx = fma(-ph.kx, zh1, fma(ph.sx, z1, ph.ox));
+	double qy = fma(-ph.ky, zh1, fma(ph.sy, z1, ph.oy));
+	return fma(qx, qx, fma(qy, qy, -c2));
+}
+
+/* ------------------------------------------------------------------ full segment (reference quadratic)
+ * src/polycap-capil.c:52-255.  Returns the reference's status; on 1, (hx,hy,hz) is the hit and (nx,ny,nz)
+ * the unit surface normal.  (p0x,p0y) = ray at z_i (phot_coord0 of src/polycap-capil.c:1256-1258). */
+template <int NE>
+PC_HD int pc_segment(const pc_tables &T, const pc_photon<NE> &ph, int i,
+                     double &p0x, double &p0y, double &hx, double &hy, double &hz,
+                     double &nx, double &ny, double &nz)
+{
+	double z0 = T.z[i], z1 = T.z[i+1];
+	double R0 = T.cap[i], R1 = T.cap[i+1];
+	double c0x = ph.kx*T.zh[i], c0y = ph.ky*T.zh[i];
+	double c1x = ph.kx*T.zh[i+1], c1y = ph.ky*T.zh[i+1];
+	double t0 = z0 - ph.Pz;
+	p0x = ph.Px + ph.dx * t0 / ph.dz;
+	p0y = ph.Py + ph.dy * t0 / ph.dz;
+	nx = 0.; ny = 0.; nz = 0.;
+	hx = hy = hz = 0.;
+	if (ph.dz < 0) return -1;          /* :85-88 */
+	if (z1 <= z0) return -1;           /* :97-100 */
+	double cdx = c1x - c0x, cdy = c1y - c0y, cdz = z1 - z0;
+	double icdz = 1.0 / cdz;
+	double ddx = ph.sx - cdx*icdz;
+	double ddy = ph.sy - cdy*icdz;
+	double rr = (R1 - R0)*icdz;
+	double qx = p0x - c0x, qy = p0y - c0y;
+	double a = ddx*ddx + ddy*ddy - rr*rr;
+	double b = 2.*qx*ddx + 2.*qy*ddy - 2.*R0*rr;
+	double c = qx*qx + qy*qy - R0*R0;
+	double discr = b*b - 4.*a*c;
+	if (discr < 0) return -2;
+	double last = ph.Pz;
+	if (discr == 0) {
+		hz = z0 + (-1.*b)/(2.*a);
+	} else {
+		double sq = sqrt(discr);
+		double i2a = 1.0/(2.*a);
+		double zr1 = z0 + (-1.*b + sq)*i2a;
+		double zr2 = z0 + (-1.*b - sq)*i2a;
+		/* written as negated "valid" tests so NaN behaves as in the reference (all comparisons false) */
+		int bad1 = (zr1 < z0) || (zr1 - last < 1.e-5) || (zr1 > z1);
+		int bad2 = (zr2 < z0) || (zr2 - last < 1.e-5) || (zr2 > z1);
+		if (bad1) {
+			if (bad2) return -3;
+			hz = zr2;
+		} else if (bad2) {
+			hz = zr1;
+		} else {
+			hz = (zr2 - last < zr1 - last) ? zr2 : zr1;
+		}
+	}
+	if (hz > z1) return -4;
+	if (hz < z0 || hz - last < 1.e-5) return -5;
+	double d_proj = (hz - z0) / ph.dz;
+	if (d_proj < 1.e-10) return -6;
+	hx = p0x + d_proj * ph.dx;
+	hy = p0y + d_proj * ph.dy;
+	/* :225-246 surface normal */
+	double s1 = qx*cdx + qy*cdy;                           /* (phot0-cap0).cap_dir, z component is 0 */
+	double s2 = ph.dx*cdx + ph.dy*cdy + ph.dz*cdz;         /* photon_dir.cap_dir */
+	double s3 = cdx*cdx + cdy*cdy + cdz*cdz;               /* |cap_dir|^2 */
+	double tpar = (d_proj + s1/s2) / (s3/s2);
+	double inx = hx - (c0x + tpar*cdx);
+	double iny = hy - (c0y + tpar*cdy);
+	double inz = hz - (z0 + tpar*cdz);
+	double idci = 1.0 / sqrt(inx*inx + iny*iny + inz*inz);
+	double idcc = 1.0 / sqrt(s3);
+	double tga = (R0 - R1) * idcc;
+	double cga = 1.0 / sqrt(1.0 + tga*tga);                /* cos(atan(t)) */
+	double sga = tga * cga;                                /* sin(atan(t)) */
+	nx = cga*inx*idci + sga*cdx*idcc;
+	ny = cga*iny*idci + sga*cdy*idcc;
+	nz = cga*inz*idci + sga*cdz*idcc;
+	pc_norm3(nx, ny, nz);
+	return 1;
+}
+
+/* ------------------------------------------------------------------ reflection
+ * src/polycap-capil.c:565-655 with polycap_refl_polar (:444-563) inlined: the geometry of the s/p split is
+ * energy independent and hoisted; per energy only the complex Fresnel amplitudes remain.
+ * cos(theta)=n.d and sin^2(theta)=1-cos^2 replace cos/sin(acos(.)); |r|^2 = |num|^2/|den|^2 replaces the
+ * complex reciprocal + cabs.  Returns 1 keep, 0 absorbed, -1 error. */
+template <int NE>
+PC_HD int pc_reflect(const pc_params &Pm, const pc_energy_const *EC, pc_photon<NE> &ph,
+                     double nx, double ny, double nz)
+{
+	double alfa = ph.dx*nx + ph.dy*ny + ph.dz*nz;
+	if (alfa < 0.) return -1;                                   /* :599-602 */
+	double ct = alfa;
+	double st2 = fma(-ct, ct, 1.0);
+	/* :520-529 */
+	double sdx = ny*ph.dz - ph.dy*nz;
+	double sdy = nz*ph.dx - ph.dz*nx;
+	double sdz = nx*ph.dy - ph.dx*ny;
+	pc_norm3(sdx, sdy, sdz);
+	double pdx = ph.dy*sdz - sdy*ph.dz;
+	double pdy = ph.dz*sdx - sdz*ph.dx;
+	double pdz = ph.dx*sdy - sdx*ph.dy;
+	pc_norm3(pdx, pdy, pdz);
+	/* :537-558 */
+	double angle_a = ph.ex*sdx + ph.ey*sdy + ph.ez*sdz;
+	double frac_s = angle_a*angle_a;
+	double frac_p = 1. - frac_s;
+	double angle_b = ph.ex*nx + ph.ey*ny + ph.ez*nz;
+	double angle_c = ph.ex*pdx + ph.ey*pdy + ph.ez*pdz;
+	double fa = angle_a*frac_s, fb = angle_b*frac_p, fc = angle_c*frac_p;
+	double f = sqrt(fa*fa + fb*fb + fc*fc);
+	double nex = fabs(ph.ex)*f, ney = fabs(ph.ey)*f, nez = fabs(ph.ez)*f;
+	pc_norm3(nex, ney, nez);
+
+	int keep = 0;
+	const int ne = (NE > 0) ? NE : Pm.n_energies;
+	for (int e = 0; e < ne; e++) {
+		const pc_energy_const ec = EC[e];
+		if (ec.valid == 0.) return -1;
+		/* tmp = n_inv^2 * sin^2 ; csq = csqrt(1 - tmp)   (:503-505) */
+		double wr = 1.0 - ec.ninv2_re*st2;
+		double wi = -ec.ninv2_im*st2;
+		double mag = sqrt(wr*wr + wi*wi);
+		double csr, csi;
+		if (wr >= 0.) {
+			csr = sqrt(0.5*(mag + wr));
+			csi = (csr > 0.) ? wi/(2.*csr) : 0.;
+		} else {
+			double sa = sqrt(0.5*(mag - wr));
+			csr = fabs(wi)/(2.*sa);
+			csi = copysign(sa, wi);
+		}
+		/* r_s = (cos - n*csq)/(cos + n*csq)   (:507-510) */
+		double tr = ec.n_re*csr - ec.n_im*csi;
+		double ti = ec.n_re*csi + ec.n_im*csr;
+		double nr = ct - tr, ni = -ti, dr = ct + tr, di = ti;
+		double r_s = (nr*nr + ni*ni) / (dr*dr + di*di);
+		/* r_p = (csq - n*cos)/(csq + n*cos)   (:512-515) */
+		double ur = ec.n_re*ct, ui = ec.n_im*ct;
+		nr = csr - ur; ni = csi - ui; dr = csr + ur; di = csi + ui;
+		double r_p = (nr*nr + ni*ni) / (dr*dr + di*di);
+		double rtot = r_s*frac_s + r_p*frac_p;
+		if (rtot < 0. || rtot > 1.) return -1;                  /* :633-637 */
+		double cons1 = ec.rough_c*alfa;                         /* (1.01358*E)*alfa*sig_rough, :626 */
+		double r_rough = (ec.rough_c == 0.) ? 1.0 : exp(-1.*cons1*cons1);
+		double we = (NE > 0) ? ph.w[e] : ph.wmem[e*ph.wstride];
+		we = we * rtot * r_rough;
+		if (NE > 0) ph.w[e] = we; else ph.wmem[e*ph.wstride] = we;
+		if (we >= 1.e-4) keep = 1;
+	}
+	ph.ex = nex; ph.ey = ney; ph.ez = nez;
+	return keep;
+}
+
+/* ------------------------------------------------------------------ EVENT: one literal segment visit
+ * src/polycap-capil.c:1246-1358 for segment ph.i, including what follows a hit.  Returns the next state. */
+template <int NE>
+PC_HD int pc_event(const pc_tables &T, const pc_params &Pm, const pc_energy_const *EC, pc_photon<NE> &ph)
+{
+	const int i = ph.i;
+	const int nmax = Pm.nmax;
+	if (i >= nmax) { ph.rc = 1; return PC_ST_DONE; }           /* :1312-1313 -> launch returns 1 */
+
+	/* :1263 capillary axis inside the optic at both ends of the segment (only boundary capillaries can fail) */
+	if (ph.bnd) {
+		if ((T.hexd[i] > 0. && pc_outside_hexd(T.hexd[i], ph.kx*T.zh[i], ph.ky*T.zh[i])) ||
+		    (T.hexd[i+1] > 0. && pc_outside_hexd(T.hexd[i+1], ph.kx*T.zh[i+1], ph.ky*T.zh[i+1]))) {
+			ph.rc = -1; return PC_ST_DONE;
+		}
+	}
+	double p0x, p0y, hx, hy, hz, nx, ny, nz;
+	int iesc = pc_segment(T, ph, i, p0x, p0y, hx, hy, hz, nx, ny, nz);
+	double cosalfa = nx*ph.dx + ny*ph.dy + nz*ph.dz;
+	if (cosalfa < 0.) iesc = -5;                                /* acos(cosalfa) > pi/2, :1270-1273 */
+
+	if (iesc != 1) {
+		/* :1296-1308 the ray at z_i must still be inside the optic (trace -3 -> launch -1) */
+		if (T.hexd[i] > 0. && pc_outside_hexd(T.hexd[i], p0x, p0y)) { ph.rc = -1; return PC_ST_DONE; }
+		ph.i = i + 1;
+		ph.first = 0;
+		ph.C0 = pc_node_C(T, ph, i + 1);
+		return PC_ST_MARCH;
+	}
+
+	/* :1277-1294 hit: still inside the optic? */
+	double cur_ext = ((T.ext[i] - T.ext[i+1])/(T.z[i] - T.z[i+1])) * (hz - T.z[i+1]) + T.ext[i+1];
+	if (Pm.mono) {
+		if (sqrt(hx*hx + hy*hy) >= cur_ext) { ph.rc = -1; return PC_ST_DONE; }
+	} else if (ph.bnd) {
+		if (pc_outside_hex(cur_ext, hx, hy)) { ph.rc = -1; return PC_ST_DONE; }
+	}
+	/* :1315-1324 */
+	double rx = hx - ph.Px, ry = hy - ph.Py, rz = hz - ph.Pz;
+	ph.dtravel += sqrt(rx*rx + ry*ry + rz*rz);
+	ph.Px = hx; ph.Py = hy; ph.Pz = hz;
+	if (fabs(cosalfa) > 1.0) { ph.rc = -1; return PC_ST_DONE; } /* :1325-1327 */
+	/* :1330-1333 rescan: last node index < nmax with z <= hit z (z strictly increasing, z_i <= hz <= z_i+1) */
+	int ix = (hz >= T.z[i+1] && i + 1 < nmax) ? i + 1 : i;
+	/* :1334-1343 */
+	cur_ext = ((T.ext[ix+1] - T.ext[ix])/(T.z[ix+1] - T.z[ix])) * (hz - T.z[ix]) + T.ext[ix];
+	if (Pm.mono) {
+		if (hx*hx + hy*hy >= cur_ext) { ph.rc = -1; return PC_ST_DONE; }
+	} else if (ph.bnd) {
+		if (pc_outside_hex(cur_ext, hx, hy)) { ph.rc = -1; return PC_ST_DONE; }
+	}
+	/* :1345-1355 */
+	int r = pc_reflect(Pm, EC, ph, nx, ny, nz);
+	if (r == 0) { ph.rc = 0; return PC_ST_DONE; }
+	if (r != 1) { ph.rc = -1; return PC_ST_DONE; }
+	ph.dx = ph.dx - 2.0*cosalfa*nx;
+	ph.dy = ph.dy - 2.0*cosalfa*ny;
+	ph.dz = ph.dz - 2.0*cosalfa*nz;
+	pc_norm3(ph.dx, ph.dy, ph.dz);
+	ph.irefl++;
+	ph.ntrace++;
+	if (ph.ntrace > nmax) { ph.rc = 1; return PC_ST_DONE; }     /* src/polycap-photon.c:912-919: at most nmax+1 calls */
+	ph.i = ix;
+	pc_trace_begin(ph);
+	return PC_ST_MARCH;
+}
+
+/* MARCH step wrapper: returns the next state (MARCH to keep going, EVENT, or DONE at the end of the optic) */
+template <int NE>
+PC_HD int pc_march_step(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph)
+{
+	if (ph.i >= Pm.nmax) { ph.rc = 1; return PC_ST_DONE; }
+	if (ph.first || Pm.literal) return PC_ST_EVENT;
+	return pc_march_ok(T, Pm, ph) ? PC_ST_MARCH : PC_ST_EVENT;
+}
+
+/* ------------------------------------------------------------------ exit window + image record
+ * src/polycap-source.c:762-777: extrapolate to z[nmax] and test the exit hexagon (mono: circle). */
+template <int NE>
+PC_HD int pc_in_exit_window(const pc_params &Pm, const pc_photon<NE> &ph)
+{
+	double t = (Pm.z_end - ph.Pz) / ph.dz;
+	double tx = ph.Px + ph.dx * t;
+	double ty = ph.Py + ph.dy * t;
+	if (Pm.mono)
+		return (sqrt(tx*tx + ty*ty) > Pm.ext_end) ? 0 : 1;
+	return pc_outside_hex(Pm.ext_end, tx, ty) ? 0 : 1;
+}
+
+#endif /* PC_DEVICE_H */

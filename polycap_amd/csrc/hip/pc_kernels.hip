@@ -1,0 +1,699 @@
+/*
+ * pc_kernels.hip -- gfx950 kernels of the photon trace path + the thin C-ABI of include/polycap-hip.h.
+ *
+ * Kernel shape (CDNA4, wave64):
+ *   - persistent waves: grid = CUs x resident blocks; every wave pulls chunks of exit-photon slots from one
+ *     global counter, every lane owns one slot at a time and retries it until a photon is transmitted
+ *     (reference driver loop src/polycap-source.c:744-884);
+ *   - profile tables (z, cap, zh, cap^2, hexd: 5 x (nmax+1) fp64 = 40 KB for nmax=999) are staged once per
+ *     workgroup into LDS; per-energy constants are wave-uniform scalar loads;
+ *   - the photon life cycle is scheduled wave-wide by phase (MARCH / EVENT / NEW) with ballots so that the
+ *     expensive, rare code (segment quadratic + Fresnel, source sampling) runs with many active lanes;
+ *   - totals are accumulated in exact 128-bit fixed point, so they do not depend on scheduling or on how
+ *     slots are split over devices.
+ * No MFMA: there is no dense contraction in this path.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "polycap-hip.h"
+#include "pc_device.h"
+#include "pc_problem.h"
+
+#define PC_BLOCK 256
+#define PC_WAVE 64
+#define PC_CHUNK 128           /* slots a wave takes from the global counter at a time */
+#define PC_FIX_SCALE 4611686018427387904.0 /* 2^62 */
+
+/* --------------------------------------------------------------------------- kernel arguments */
+
+struct pc_img_planes {
+	double *src_start[2], *pc_start[2], *pc_start_dir[2], *pc_start_elecv[2];
+	double *pc_exit[3], *pc_exit_dir[2], *pc_exit_elecv[2];
+	long long *nrefl;
+	double *dtravel;
+	double *weights;           /* [n_slots * n_energies] */
+};
+
+struct pc_totals {             /* device-resident totals of one run */
+	unsigned long long counters[8];   /* iexit, not_entered, not_transmitted, sum_irefl, failed_slots, launches */
+	unsigned long long next_slot;     /* work counter (relative slot index) */
+	unsigned long long pad;
+	/* followed by 2*n_energies u64: (lo, hi) fixed-point weight sums */
+};
+
+struct pc_kargs {
+	const double *g_z, *g_cap, *g_zh, *g_cap2, *g_hexd, *g_ext;
+	const pc_energy_const *ec;
+	pc_params pm;
+	unsigned long long seed;
+	long long slot0, n_slots;
+	unsigned int max_attempts;
+	int keep_images;
+	int event_threshold;
+	int march_burst;
+	pc_totals *totals;
+	unsigned long long *sumw;     /* 2*n_energies */
+	pc_img_planes img;
+	double *wscratch;             /* NE==0: n_energies * total_threads */
+	long long total_threads;
+	/* explicit-photon mode */
+	const double *in_start, *in_dir, *in_elecv;
+	int *out_rc;
+	double *out_weights, *out_exit_coords, *out_exit_dir, *out_exit_elecv, *out_dtravel;
+	long long *out_irefl;
+};
+
+/* lane states on top of pc_device.h's: what the NEW phase has to do for the lane */
+enum { LS_IDLE = 0, LS_NEED_SLOT = 1, LS_START = 5, LS_MARCH = PC_ST_MARCH, LS_EVENT = PC_ST_EVENT, LS_DONE = PC_ST_DONE };
+
+__device__ __forceinline__ unsigned long long pc_wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		v += __shfl_xor(v, off, PC_WAVE);
+	return v;
+}
+
+/* exact add of a 128-bit (hi:lo) value to a global (lo,hi) pair; carries are derived from each add's old value */
+__device__ __forceinline__ void pc_atomic_add128(unsigned long long *lohi, unsigned long long lo, unsigned long long hi)
+{
+	unsigned long long old = atomicAdd(&lohi[0], lo);
+	unsigned long long carry = (old + lo < old) ? 1ull : 0ull;
+	if (hi + carry) atomicAdd(&lohi[1], hi + carry);
+}
+
+/* --------------------------------------------------------------------------- the trace kernel
+ * NE > 0: NE energies, weights in registers.  NE == 0: any n_energies, weights in wscratch.
+ * MODE: PC_MODE_EXPLICIT: photons come from in_start/in_dir/in_elecv (polycap_photon_launch), no retry, no
+ * source; PC_MODE_SRC_CIRCULAR / _GENERIC: photons are sampled from the source (circular / elliptical). */
+enum { PC_MODE_SRC_CIRCULAR = 0, PC_MODE_SRC_GENERIC = 1, PC_MODE_EXPLICIT = 2 };
+
+template <int NE, int MODE>
+__global__ void __launch_bounds__(PC_BLOCK)
+pc_trace_kernel(pc_kargs a)
+{
+	constexpr bool EXPLICIT = (MODE == PC_MODE_EXPLICIT);
+	extern __shared__ double lds[];
+	const int npts = a.pm.nmax + 1;
+	double *l_z = lds, *l_cap = lds + npts, *l_zh = lds + 2*npts, *l_cap2 = lds + 3*npts, *l_hexd = lds + 4*npts;
+	for (int k = threadIdx.x; k < npts; k += blockDim.x) {
+		l_z[k] = a.g_z[k];
+		l_cap[k] = a.g_cap[k];
+		l_zh[k] = a.g_zh[k];
+		l_cap2[k] = a.g_cap2[k];
+		l_hexd[k] = a.g_hexd[k];
+	}
+	__syncthreads();
+	pc_tables T;
+	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.hexd = l_hexd; T.ext = a.g_ext;
+	const pc_params &Pm = a.pm;
+	const int ne = (NE > 0) ? NE : Pm.n_energies;
+	const int lane = threadIdx.x & (PC_WAVE - 1);
+	const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+
+	pc_photon<NE> ph;
+	ph.wmem = (NE > 0) ? nullptr : (a.wscratch + gtid);
+	ph.wstride = (long)a.total_threads;
+	ph.rc = 0;
+
+	int state = LS_NEED_SLOT;
+	long long slot = -1;          /* relative slot index in [0, n_slots) */
+	unsigned int attempt = 0;
+	double c_ae = 1., c_be = 0.;   /* projection constants of the start electric vector (src/polycap-source.c:789-796) */
+	/* wave-uniform chunk of slots */
+	long long chunk_next = 0, chunk_end = 0;
+
+	/* per-lane totals */
+	unsigned long long n_exit = 0, n_not_entered = 0, n_not_trans = 0, s_irefl = 0, n_failed = 0, n_launch = 0;
+	unsigned long long acc_lo[NE > 0 ? NE : 1], acc_hi[NE > 0 ? NE : 1];
+#pragma unroll
+	for (int e = 0; e < (NE > 0 ? NE : 1); e++) { acc_lo[e] = 0; acc_hi[e] = 0; }
+
+	for (;;) {
+		const unsigned long long mM = __ballot(state == LS_MARCH);
+		const unsigned long long mE = __ballot(state == LS_EVENT);
+		const unsigned long long mN = __ballot(state == LS_DONE || state == LS_NEED_SLOT || state == LS_START);
+		if ((mM | mE | mN) == 0ull) break;
+		const int nM = __popcll(mM), nE = __popcll(mE), nN = __popcll(mN);
+
+		if (nM > 0 && (nM >= a.event_threshold || (nE == 0 && nN == 0))) {
+			/* ---------------- MARCH burst: certified node skipping, 6 FMA + 3 LDS reads per node */
+			for (int b = 0; b < a.march_burst; b++) {
+				if (state == LS_MARCH)
+					state = pc_march_step(T, Pm, ph);
+				if (__popcll(__ballot(state == LS_MARCH)) < a.event_threshold) break;
+			}
+		} else if (nE > 0 && nE >= nN) {
+			/* ---------------- EVENT: full quadratic of one segment (+ wall hit, Fresnel reflection) */
+			if (state == LS_EVENT)
+				state = pc_event(T, Pm, a.ec, ph);
+		} else if (nN > 0) {
+			/* ---------------- NEW: finalise finished photons, hand out slots, sample + entrance tests */
+			if (state == LS_DONE) {
+				const int rc = ph.rc;
+				if (EXPLICIT) {
+					const long long j = slot;
+					a.out_rc[j] = rc;
+					for (int e = 0; e < ne; e++)
+						a.out_weights[j*ne + e] = (NE > 0) ? ph.w[NE > 0 ? e : 0] : ph.wmem[e*ph.wstride];
+					a.out_exit_coords[3*j] = ph.Px; a.out_exit_coords[3*j+1] = ph.Py; a.out_exit_coords[3*j+2] = ph.Pz;
+					a.out_exit_dir[3*j] = ph.dx; a.out_exit_dir[3*j+1] = ph.dy; a.out_exit_dir[3*j+2] = ph.dz;
+					a.out_exit_elecv[3*j] = ph.ex; a.out_exit_elecv[3*j+1] = ph.ey; a.out_exit_elecv[3*j+2] = ph.ez;
+					a.out_irefl[j] = ph.irefl;
+					a.out_dtravel[j] = ph.dtravel;
+					state = LS_NEED_SLOT;
+				} else {
+					/* src/polycap-source.c:758-777 */
+					int ok = 0;
+					if (rc == 0) n_not_trans++;
+					else if (rc == 2) n_not_entered++;
+					else if (rc == 1) ok = pc_in_exit_window(Pm, ph);
+					if (ok) {
+						n_exit++;
+						s_irefl += (unsigned long long)ph.irefl;
+						for (int e = 0; e < ne; e++) {
+							double w = (NE > 0) ? ph.w[NE > 0 ? e : 0] : ph.wmem[e*ph.wstride];
+							unsigned long long f = (unsigned long long)(w * PC_FIX_SCALE);
+							if (NE > 0) {
+								unsigned long long old = acc_lo[NE > 0 ? e : 0];
+								acc_lo[NE > 0 ? e : 0] = old + f;
+								acc_hi[NE > 0 ? e : 0] += (old + f < old) ? 1ull : 0ull;
+							} else {
+								pc_atomic_add128(a.sumw + 2*e, f, 0ull);
+							}
+							if (a.keep_images) a.img.weights[slot*ne + e] = w;
+						}
+						if (a.keep_images) {
+							/* src/polycap-source.c:900-923 */
+							const long long j = slot;
+							double t = (Pm.z_end - ph.Pz) / ph.dz;
+							double ex = ph.Px + ph.dx*t, ey = ph.Py + ph.dy*t, ez = ph.Pz + ph.dz*t;
+							a.img.pc_exit[0][j] = ex; a.img.pc_exit[1][j] = ey; a.img.pc_exit[2][j] = ez;
+							a.img.pc_exit_dir[0][j] = ph.dx; a.img.pc_exit_dir[1][j] = ph.dy;
+							double tx = ph.ex*c_ae + ph.dx*c_be, ty = ph.ey*c_ae + ph.dy*c_be, tz = ph.ez*c_ae + ph.dz*c_be;
+							pc_norm3(tx, ty, tz);
+							a.img.pc_exit_elecv[0][j] = round(tx); a.img.pc_exit_elecv[1][j] = round(ty);
+							a.img.nrefl[j] = ph.irefl;
+							double lx = ex - ph.Px, ly = ey - ph.Py, lz = Pm.z_end - ph.Pz;
+							a.img.dtravel[j] = ph.dtravel + sqrt(lx*lx + ly*ly + lz*lz);
+						}
+						state = LS_NEED_SLOT;
+					} else {
+						attempt++;
+						if (attempt >= a.max_attempts) {
+							n_failed++;
+							if (a.keep_images)
+								for (int e = 0; e < ne; e++) a.img.weights[slot*ne + e] = 0.;
+							state = LS_NEED_SLOT;
+						} else {
+							state = LS_START;
+						}
+					}
+				}
+			}
+			/* hand out slots: wave-uniform chunk, refilled from the global counter by one lane */
+			{
+				const unsigned long long need = __ballot(state == LS_NEED_SLOT);
+				if (need) {
+					const int k = __popcll(need);
+					if (chunk_end - chunk_next < k) {
+						/* top up: take what is left of the old chunk first, then a fresh chunk */
+						long long have = chunk_end - chunk_next;
+						long long base_new = 0;
+						if (lane == 0) base_new = (long long)atomicAdd(&a.totals->next_slot, (unsigned long long)PC_CHUNK);
+						base_new = __shfl(base_new, 0, PC_WAVE);
+						const int rank = __popcll(need & ((1ull << lane) - 1ull));
+						if (state == LS_NEED_SLOT) {
+							slot = (rank < have) ? (chunk_next + rank) : (base_new + (rank - have));
+						}
+						chunk_next = base_new + (k - have);
+						chunk_end = base_new + PC_CHUNK;
+					} else {
+						const int rank = __popcll(need & ((1ull << lane) - 1ull));
+						if (state == LS_NEED_SLOT) slot = chunk_next + rank;
+						chunk_next += k;
+					}
+					if (state == LS_NEED_SLOT) {
+						if (slot >= a.n_slots) { state = LS_IDLE; }
+						else { attempt = 0; state = LS_START; }
+					}
+				}
+			}
+			/* start an attempt */
+			if (state == LS_START) {
+				n_launch++;
+				if (EXPLICIT) {
+					const long long j = slot;
+					state = pc_launch_init(T, Pm, ph, a.in_start[3*j], a.in_start[3*j+1], a.in_start[3*j+2],
+					                       a.in_dir[3*j], a.in_dir[3*j+1], a.in_dir[3*j+2],
+					                       a.in_elecv[3*j], a.in_elecv[3*j+1], a.in_elecv[3*j+2]);
+				} else {
+					pc_start s;
+					pc_sample_photon<MODE == PC_MODE_SRC_GENERIC>(Pm, a.seed, (unsigned long long)(a.slot0 + slot), attempt, s);
+					state = pc_launch_init(T, Pm, ph, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez);
+					if (state == LS_MARCH) {
+						/* src/polycap-source.c:779-798: start images of the attempt that is now inside a capillary;
+						 * the slot belongs to this lane, so a later (transmitted) attempt simply overwrites them */
+						double cosalpha = s.ex*s.dx + s.ey*s.dy + s.ez*s.dz;
+						c_ae = 1.0 / sqrt(1.0 - cosalpha*cosalpha);
+						c_be = -1.*c_ae*cosalpha;
+						if (a.keep_images) {
+							const long long j = slot;
+							a.img.src_start[0][j] = s.srcx; a.img.src_start[1][j] = s.srcy;
+							a.img.pc_start[0][j] = s.x; a.img.pc_start[1][j] = s.y;
+							a.img.pc_start_dir[0][j] = s.dx; a.img.pc_start_dir[1][j] = s.dy;
+							double tx = s.ex*c_ae + s.dx*c_be, ty = s.ey*c_ae + s.dy*c_be, tz = s.ez*c_ae + s.dz*c_be;
+							pc_norm3(tx, ty, tz);
+							a.img.pc_start_elecv[0][j] = round(tx); a.img.pc_start_elecv[1][j] = round(ty);
+						}
+					}
+				}
+			}
+		} else {
+			/* nM > 0 but below the threshold and nothing else pending is handled by the first branch;
+			 * reaching here means only MARCH lanes below threshold with events pending < new: run events/new next */
+			if (state == LS_EVENT)
+				state = pc_event(T, Pm, a.ec, ph);
+		}
+	}
+
+	if (!EXPLICIT) {
+		/* one set of atomics per wave */
+		unsigned long long v0 = pc_wave_sum_u64(n_exit), v1 = pc_wave_sum_u64(n_not_entered), v2 = pc_wave_sum_u64(n_not_trans);
+		unsigned long long v3 = pc_wave_sum_u64(s_irefl), v4 = pc_wave_sum_u64(n_failed), v5 = pc_wave_sum_u64(n_launch);
+		if (lane == 0) {
+			atomicAdd(&a.totals->counters[0], v0);
+			atomicAdd(&a.totals->counters[1], v1);
+			atomicAdd(&a.totals->counters[2], v2);
+			atomicAdd(&a.totals->counters[3], v3);
+			if (v4) atomicAdd(&a.totals->counters[4], v4);
+			atomicAdd(&a.totals->counters[5], v5);
+		}
+		if (NE > 0) {
+#pragma unroll
+			for (int e = 0; e < (NE > 0 ? NE : 1); e++) {
+				/* exact wave sum of 128-bit values through three 64-bit partial sums */
+				unsigned long long s_hi = pc_wave_sum_u64(acc_hi[e]);
+				unsigned long long s_mid = pc_wave_sum_u64(acc_lo[e] >> 32);
+				unsigned long long s_low = pc_wave_sum_u64(acc_lo[e] & 0xffffffffull);
+				if (lane == 0) {
+					unsigned long long lo = s_low + (s_mid << 32);
+					unsigned long long hi = s_hi + (s_mid >> 32) + ((lo < s_low) ? 1ull : 0ull);
+					pc_atomic_add128(a.sumw + 2*e, lo, hi);
+				}
+			}
+		}
+	}
+}
+
+/* source sampling only (parity of polycap_source_get_photon) */
+__global__ void pc_sample_kernel(pc_params pm, unsigned long long seed, long long n,
+                                 const long long *slots, const unsigned int *attempts, double *out)
+{
+	long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n) return;
+	pc_start s;
+	if (pm.generic_src) pc_sample_photon<true>(pm, seed, (unsigned long long)slots[j], attempts[j], s);
+	else pc_sample_photon<false>(pm, seed, (unsigned long long)slots[j], attempts[j], s);
+	double *o = out + 12*j;
+	o[0] = s.x; o[1] = s.y; o[2] = s.z; o[3] = s.dx; o[4] = s.dy; o[5] = s.dz;
+	o[6] = s.ex; o[7] = s.ey; o[8] = s.ez; o[9] = s.srcx; o[10] = s.srcy; o[11] = 0.;
+}
+
+/* =========================================================================== host side (C-ABI) */
+
+static thread_local std::string g_last_error;
+
+static int pc_fail(int code, const std::string &msg)
+{
+	g_last_error = msg;
+	return code;
+}
+
+#define PC_HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) \
+	return pc_fail(PC_HIP_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+
+struct pc_hip_ctx {
+	int device = 0;
+	int n_cu = 256;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	pc_host_tables host;
+	double *d_tables = nullptr;            /* z, cap, zh, cap2, hexd, ext: 6 x npts */
+	pc_energy_const *d_ec = nullptr;
+	/* options */
+	int literal = 0;
+	int event_threshold = 40;
+	int march_burst = 64;
+	int blocks_per_cu = 4;
+	/* last run */
+	pc_totals *d_totals = nullptr;         /* pc_totals + 2*nE u64 */
+	size_t totals_bytes = 0;
+	double *d_img = nullptr;               /* 17 planes x n_slots (+ weights) */
+	long long img_slots = 0;
+	int img_valid = 0;
+	double *d_wscratch = nullptr;
+	size_t wscratch_elems = 0;
+	long long run_slots = 0;
+	int run_pending = 0;
+	float last_ms = 0.f;
+};
+
+static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
+{
+	const size_t npts = (size_t)ctx->host.pm.nmax + 1;
+	memset(&a, 0, sizeof(a));
+	a.g_z = ctx->d_tables; a.g_cap = ctx->d_tables + npts; a.g_zh = ctx->d_tables + 2*npts;
+	a.g_cap2 = ctx->d_tables + 3*npts; a.g_hexd = ctx->d_tables + 4*npts; a.g_ext = ctx->d_tables + 5*npts;
+	a.ec = ctx->d_ec;
+	a.pm = ctx->host.pm;
+	a.pm.literal = ctx->literal;
+	a.event_threshold = ctx->event_threshold;
+	a.march_burst = ctx->march_burst;
+	a.totals = ctx->d_totals;
+	a.sumw = (unsigned long long *)(ctx->d_totals + 1);
+}
+
+template <int NE, int MODE>
+static int pc_launch_one(pc_hip_ctx *ctx, const pc_kargs &a, int grid, size_t lds_bytes)
+{
+	PC_HIP_CHECK(hipFuncSetAttribute((const void *)pc_trace_kernel<NE, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+	hipLaunchKernelGGL((pc_trace_kernel<NE, MODE>), dim3(grid), dim3(PC_BLOCK), lds_bytes, ctx->stream, a);
+	PC_HIP_CHECK(hipGetLastError());
+	return PC_HIP_OK;
+}
+
+template <int MODE>
+static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
+{
+	const int ne = ctx->host.pm.n_energies;
+	const size_t npts = (size_t)ctx->host.pm.nmax + 1;
+	const size_t lds_bytes = 5*npts*sizeof(double);
+	long long max_blocks = (long long)ctx->n_cu * ctx->blocks_per_cu;
+	long long want_blocks = (n_items + PC_BLOCK - 1) / PC_BLOCK;
+	int grid = (int)(want_blocks < max_blocks ? want_blocks : max_blocks);
+	if (grid < 1) grid = 1;
+	a.total_threads = (long long)grid * PC_BLOCK;
+	if (ne != 1) {
+		size_t need = (size_t)ne * (size_t)a.total_threads;
+		if (need > ctx->wscratch_elems) {
+			if (ctx->d_wscratch) PC_HIP_CHECK(hipFree(ctx->d_wscratch));
+			ctx->d_wscratch = nullptr; ctx->wscratch_elems = 0;
+			hipError_t e = hipMalloc(&ctx->d_wscratch, need*sizeof(double));
+			if (e != hipSuccess) return pc_fail(PC_HIP_ERR_MEMORY, "could not allocate the per-lane weight scratch");
+			ctx->wscratch_elems = need;
+		}
+		a.wscratch = ctx->d_wscratch;
+	}
+	PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+	int st = (ne == 1) ? pc_launch_one<1, MODE>(ctx, a, grid, lds_bytes) : pc_launch_one<0, MODE>(ctx, a, grid, lds_bytes);
+	if (st) return st;
+	PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+	return PC_HIP_OK;
+}
+
+extern "C" {
+
+int pc_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+const char *pc_hip_last_error(void)
+{
+	return g_last_error.c_str();
+}
+
+void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+	if (ctx->d_ec) (void)hipFree(ctx->d_ec);
+	if (ctx->d_totals) (void)hipFree(ctx->d_totals);
+	if (ctx->d_img) (void)hipFree(ctx->d_img);
+	if (ctx->d_wscratch) (void)hipFree(ctx->d_wscratch);
+	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **out)
+{
+	if (!out) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_ctx_create: ctx must not be NULL");
+	*out = nullptr;
+	int ndev = pc_hip_device_count();
+	if (ndev <= 0) return pc_fail(PC_HIP_ERR_NO_DEVICE, "pc_hip_ctx_create: no HIP device available (the trace path has no CPU fallback)");
+	if (device < 0 || device >= ndev) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_ctx_create: device index out of range");
+	pc_hip_ctx *ctx = new pc_hip_ctx();
+	ctx->device = device;
+	std::string err;
+	int rc = pc_build_tables(problem, ctx->host, err);
+	if (rc) { delete ctx; return pc_fail(rc, "pc_hip_ctx_create: " + err); }
+	const size_t npts = (size_t)ctx->host.pm.nmax + 1;
+	if (5*npts*sizeof(double) > 160*1024) { delete ctx; return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_ctx_create: profile too long for the 160 KB LDS (nmax <= 4095)"); }
+#define PC_CTX_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); pc_hip_ctx_destroy(ctx); return pc_fail(PC_HIP_ERR_RUNTIME, m); } } while (0)
+	PC_CTX_CHECK(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	PC_CTX_CHECK(hipGetDeviceProperties(&prop, device));
+	ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	PC_CTX_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+	PC_CTX_CHECK(hipEventCreate(&ctx->ev0));
+	PC_CTX_CHECK(hipEventCreate(&ctx->ev1));
+	PC_CTX_CHECK(hipMalloc(&ctx->d_tables, 6*npts*sizeof(double)));
+	const std::vector<double> *src[6] = { &ctx->host.z, &ctx->host.cap, &ctx->host.zh, &ctx->host.cap2, &ctx->host.hexd, &ctx->host.ext };
+	for (int k = 0; k < 6; k++)
+		PC_CTX_CHECK(hipMemcpy(ctx->d_tables + k*npts, src[k]->data(), npts*sizeof(double), hipMemcpyHostToDevice));
+	PC_CTX_CHECK(hipMalloc(&ctx->d_ec, ctx->host.ec.size()*sizeof(pc_energy_const)));
+	PC_CTX_CHECK(hipMemcpy(ctx->d_ec, ctx->host.ec.data(), ctx->host.ec.size()*sizeof(pc_energy_const), hipMemcpyHostToDevice));
+	ctx->totals_bytes = sizeof(pc_totals) + 2*ctx->host.ec.size()*sizeof(unsigned long long);
+	PC_CTX_CHECK(hipMalloc(&ctx->d_totals, ctx->totals_bytes));
+	PC_CTX_CHECK(hipMemset(ctx->d_totals, 0, ctx->totals_bytes));
+#undef PC_CTX_CHECK
+	*out = ctx;
+	return PC_HIP_OK;
+}
+
+int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
+{
+	if (!ctx || !name) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_set_option: NULL argument");
+	std::string n(name);
+	if (n == "literal_march") ctx->literal = value ? 1 : 0;
+	else if (n == "event_threshold") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "event_threshold must be in [1,64]"); ctx->event_threshold = (int)value; }
+	else if (n == "march_burst") { if (value < 1) return pc_fail(PC_HIP_ERR_INVALID, "march_burst must be >= 1"); ctx->march_burst = (int)value; }
+	else if (n == "blocks_per_cu") { if (value < 1 || value > 8) return pc_fail(PC_HIP_ERR_INVALID, "blocks_per_cu must be in [1,8]"); ctx->blocks_per_cu = (int)value; }
+	else return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_set_option: unknown option " + n);
+	return PC_HIP_OK;
+}
+
+int pc_hip_launch_photons(pc_hip_ctx *ctx, int64_t n, const double *start_coords, const double *start_dir, const double *start_elecv,
+                          int32_t *rc, double *weights, double *exit_coords, double *exit_dir, double *exit_elecv,
+                          int64_t *i_refl, double *d_travel)
+{
+	if (!ctx || n < 0 || !start_coords || !start_dir || !start_elecv || !rc || !weights || !exit_coords || !exit_dir || !exit_elecv || !i_refl || !d_travel)
+		return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_launch_photons: NULL argument");
+	if (n == 0) return PC_HIP_OK;
+	PC_HIP_CHECK(hipSetDevice(ctx->device));
+	const size_t ne = (size_t)ctx->host.pm.n_energies;
+	const size_t N = (size_t)n;
+	/* one device buffer: 3 inputs [3N], rc [N ints padded], weights [N*ne], 3 outputs [3N], irefl [N], dtravel [N] */
+	size_t doubles = 9*N + N + N*ne + 9*N + N + N;
+	double *d = nullptr;
+	if (hipMalloc(&d, doubles*sizeof(double)) != hipSuccess) return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_launch_photons: device allocation failed");
+	double *d_start = d, *d_dir = d + 3*N, *d_ev = d + 6*N;
+	int *d_rc = (int *)(d + 9*N);
+	double *d_w = d + 10*N, *d_ec = d_w + N*ne, *d_ed = d_ec + 3*N, *d_ee = d_ed + 3*N;
+	long long *d_ir = (long long *)(d_ee + 3*N);
+	double *d_dt = (double *)(d_ir + N);
+	int status = PC_HIP_OK;
+#define PC_LP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { status = pc_fail(PC_HIP_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e)); goto done; } } while (0)
+	{
+		PC_LP_CHECK(hipMemcpyAsync(d_start, start_coords, 3*N*sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+		PC_LP_CHECK(hipMemcpyAsync(d_dir, start_dir, 3*N*sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+		PC_LP_CHECK(hipMemcpyAsync(d_ev, start_elecv, 3*N*sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+		PC_LP_CHECK(hipMemsetAsync(ctx->d_totals, 0, ctx->totals_bytes, ctx->stream));
+		pc_kargs a;
+		pc_fill_common(ctx, a);
+		a.n_slots = n; a.slot0 = 0; a.max_attempts = 1; a.keep_images = 0;
+		a.in_start = d_start; a.in_dir = d_dir; a.in_elecv = d_ev;
+		a.out_rc = d_rc; a.out_weights = d_w; a.out_exit_coords = d_ec; a.out_exit_dir = d_ed; a.out_exit_elecv = d_ee;
+		a.out_irefl = d_ir; a.out_dtravel = d_dt;
+		status = pc_launch_kernel<PC_MODE_EXPLICIT>(ctx, a, n);
+		if (status) goto done;
+		PC_LP_CHECK(hipMemcpyAsync(rc, d_rc, N*sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+		PC_LP_CHECK(hipMemcpyAsync(weights, d_w, N*ne*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		PC_LP_CHECK(hipMemcpyAsync(exit_coords, d_ec, 3*N*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		PC_LP_CHECK(hipMemcpyAsync(exit_dir, d_ed, 3*N*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		PC_LP_CHECK(hipMemcpyAsync(exit_elecv, d_ee, 3*N*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		PC_LP_CHECK(hipMemcpyAsync(i_refl, d_ir, N*sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+		PC_LP_CHECK(hipMemcpyAsync(d_travel, d_dt, N*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		PC_LP_CHECK(hipStreamSynchronize(ctx->stream));
+	}
+done:
+#undef PC_LP_CHECK
+	(void)hipFree(d);
+	ctx->img_valid = 0;
+	return status;
+}
+
+int pc_hip_sample_photons(pc_hip_ctx *ctx, uint64_t seed, int64_t n, const int64_t *slots, const uint32_t *attempts, double *out)
+{
+	if (!ctx || n < 0 || !slots || !attempts || !out) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_sample_photons: NULL argument");
+	if (n == 0) return PC_HIP_OK;
+	PC_HIP_CHECK(hipSetDevice(ctx->device));
+	const size_t N = (size_t)n;
+	long long *d_slots = nullptr; unsigned int *d_att = nullptr; double *d_out = nullptr;
+	int status = PC_HIP_OK;
+	if (hipMalloc(&d_slots, N*sizeof(long long)) != hipSuccess || hipMalloc(&d_att, N*sizeof(unsigned int)) != hipSuccess ||
+	    hipMalloc(&d_out, 12*N*sizeof(double)) != hipSuccess) {
+		status = pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_sample_photons: device allocation failed");
+	} else {
+		hipError_t e = hipMemcpy(d_slots, slots, N*sizeof(long long), hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = hipMemcpy(d_att, attempts, N*sizeof(unsigned int), hipMemcpyHostToDevice);
+		if (e == hipSuccess) {
+			hipLaunchKernelGGL(pc_sample_kernel, dim3((unsigned)((N + 255)/256)), dim3(256), 0, ctx->stream,
+			                   ctx->host.pm, (unsigned long long)seed, (long long)n, d_slots, d_att, d_out);
+			e = hipGetLastError();
+		}
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		if (e == hipSuccess) e = hipMemcpy(out, d_out, 12*N*sizeof(double), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_sample_photons: ") + hipGetErrorString(e));
+	}
+	if (d_slots) (void)hipFree(d_slots);
+	if (d_att) (void)hipFree(d_att);
+	if (d_out) (void)hipFree(d_out);
+	return status;
+}
+
+/* image planes: 17 double-sized planes of n_slots entries followed by the weights plane */
+static const int PC_N_PLANES = 17;
+
+int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64_t n_slots, uint32_t max_attempts, int keep_images)
+{
+	if (!ctx) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_run: ctx must not be NULL");
+	if (n_slots < 1 || slot0 < 0) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_run: n_slots must be >= 1 and slot0 >= 0");
+	if (max_attempts < 1) max_attempts = 1;
+	PC_HIP_CHECK(hipSetDevice(ctx->device));
+	const size_t ne = (size_t)ctx->host.pm.n_energies;
+	pc_kargs a;
+	pc_fill_common(ctx, a);
+	ctx->img_valid = 0;
+	if (keep_images) {
+		if (ctx->img_slots < n_slots) {
+			if (ctx->d_img) PC_HIP_CHECK(hipFree(ctx->d_img));
+			ctx->d_img = nullptr; ctx->img_slots = 0;
+			size_t bytes = ((size_t)PC_N_PLANES + ne) * (size_t)n_slots * sizeof(double);
+			if (hipMalloc(&ctx->d_img, bytes) != hipSuccess)
+				return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_run: could not allocate the image planes; use keep_images=0");
+			ctx->img_slots = n_slots;
+		}
+		double *p = ctx->d_img;
+		const size_t S = (size_t)ctx->img_slots;
+		a.img.src_start[0] = p; a.img.src_start[1] = p + S;
+		a.img.pc_start[0] = p + 2*S; a.img.pc_start[1] = p + 3*S;
+		a.img.pc_start_dir[0] = p + 4*S; a.img.pc_start_dir[1] = p + 5*S;
+		a.img.pc_start_elecv[0] = p + 6*S; a.img.pc_start_elecv[1] = p + 7*S;
+		a.img.pc_exit[0] = p + 8*S; a.img.pc_exit[1] = p + 9*S; a.img.pc_exit[2] = p + 10*S;
+		a.img.pc_exit_dir[0] = p + 11*S; a.img.pc_exit_dir[1] = p + 12*S;
+		a.img.pc_exit_elecv[0] = p + 13*S; a.img.pc_exit_elecv[1] = p + 14*S;
+		a.img.nrefl = (long long *)(p + 15*S);
+		a.img.dtravel = p + 16*S;
+		a.img.weights = p + 17*S;
+	}
+	PC_HIP_CHECK(hipMemsetAsync(ctx->d_totals, 0, ctx->totals_bytes, ctx->stream));
+	a.seed = seed; a.slot0 = slot0; a.n_slots = n_slots; a.max_attempts = max_attempts; a.keep_images = keep_images ? 1 : 0;
+	int status = ctx->host.pm.generic_src ? pc_launch_kernel<PC_MODE_SRC_GENERIC>(ctx, a, n_slots)
+	                                        : pc_launch_kernel<PC_MODE_SRC_CIRCULAR>(ctx, a, n_slots);
+	if (status) return status;
+	ctx->run_slots = n_slots;
+	ctx->run_pending = 1;
+	ctx->img_valid = keep_images ? 1 : 0;
+	return PC_HIP_OK;
+}
+
+int pc_hip_transmission_wait(pc_hip_ctx *ctx, float *kernel_ms)
+{
+	if (!ctx) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_wait: ctx must not be NULL");
+	PC_HIP_CHECK(hipSetDevice(ctx->device));
+	PC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if (ctx->run_pending) {
+		float ms = 0.f;
+		PC_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+		ctx->last_ms = ms;
+		ctx->run_pending = 0;
+	}
+	if (kernel_ms) *kernel_ms = ctx->last_ms;
+	return PC_HIP_OK;
+}
+
+double pc_hip_fixed_to_double(uint64_t lo, uint64_t hi)
+{
+	long double v = (long double)hi * 18446744073709551616.0L + (long double)lo;
+	return (double)(v / 4611686018427387904.0L);
+}
+
+int pc_hip_transmission_totals(pc_hip_ctx *ctx, double *sum_weights, int64_t counters[6], uint64_t *sumw_fixed)
+{
+	if (!ctx) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_totals: ctx must not be NULL");
+	int st = pc_hip_transmission_wait(ctx, nullptr);
+	if (st) return st;
+	std::vector<unsigned char> buf(ctx->totals_bytes);
+	PC_HIP_CHECK(hipMemcpy(buf.data(), ctx->d_totals, ctx->totals_bytes, hipMemcpyDeviceToHost));
+	const pc_totals *t = (const pc_totals *)buf.data();
+	const unsigned long long *sw = (const unsigned long long *)(t + 1);
+	const size_t ne = (size_t)ctx->host.pm.n_energies;
+	if (counters)
+		for (int k = 0; k < 6; k++) counters[k] = (int64_t)t->counters[k];
+	for (size_t e = 0; e < ne; e++) {
+		if (sum_weights) sum_weights[e] = pc_hip_fixed_to_double(sw[2*e], sw[2*e+1]);
+		if (sumw_fixed) { sumw_fixed[2*e] = sw[2*e]; sumw_fixed[2*e+1] = sw[2*e+1]; }
+	}
+	if (t->counters[4] != 0)
+		return pc_fail(PC_HIP_ERR_ATTEMPTS, "pc_hip_transmission_totals: some slots exhausted max_attempts without a transmitted photon");
+	return PC_HIP_OK;
+}
+
+int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const pc_hip_images *dst)
+{
+	if (!ctx || !dst) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: NULL argument");
+	if (!ctx->img_valid) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: the last run kept no images");
+	if (first < 0 || count < 0 || first + count > ctx->run_slots) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: slot range out of bounds");
+	int st = pc_hip_transmission_wait(ctx, nullptr);
+	if (st) return st;
+	if (count == 0) return PC_HIP_OK;
+	const size_t S = (size_t)ctx->img_slots, ne = (size_t)ctx->host.pm.n_energies;
+	const double *p = ctx->d_img;
+	void *planes[PC_N_PLANES] = {
+		dst->src_start_coords[0], dst->src_start_coords[1], dst->pc_start_coords[0], dst->pc_start_coords[1],
+		dst->pc_start_dir[0], dst->pc_start_dir[1], dst->pc_start_elecv[0], dst->pc_start_elecv[1],
+		dst->pc_exit_coords[0], dst->pc_exit_coords[1], dst->pc_exit_coords[2],
+		dst->pc_exit_dir[0], dst->pc_exit_dir[1], dst->pc_exit_elecv[0], dst->pc_exit_elecv[1],
+		dst->pc_exit_nrefl, dst->pc_exit_dtravel };
+	for (int k = 0; k < PC_N_PLANES; k++)
+		if (planes[k])
+			PC_HIP_CHECK(hipMemcpy(planes[k], p + (size_t)k*S + (size_t)first, (size_t)count*sizeof(double), hipMemcpyDeviceToHost));
+	if (dst->exit_coord_weights)
+		PC_HIP_CHECK(hipMemcpy(dst->exit_coord_weights, p + 17*S + (size_t)first*ne, (size_t)count*ne*sizeof(double), hipMemcpyDeviceToHost));
+	return PC_HIP_OK;
+}
+
+/* src/polycap-source.c:1066-1076 */
+void pc_hip_efficiencies(size_t n_energies, const double *sum_weights, const int64_t counters[6], double *efficiencies)
+{
+	int64_t sum_iexit = counters[0], sum_not_entered = counters[1], sum_not_transmitted = counters[2];
+	double open_area = (double)(sum_iexit+sum_not_transmitted)/(sum_iexit+sum_not_entered+sum_not_transmitted);
+	for (size_t i = 0; i < n_energies; i++)
+		efficiencies[i] = (sum_weights[i] / ((double)sum_iexit+(double)sum_not_transmitted)) * open_area;
+}
+
+} /* extern "C" */

@@ -1,0 +1,107 @@
+/*
+ * pc_problem.h -- host-side construction of the device tables from a pc_hip_problem (plain C++, no HIP).
+ *
+ * Derived tables (all fp64, nmax+1 entries):
+ *   zh[i]   = ext[i] / (2 cos(pi/6) (n_shells+1))     hex-grid pitch: capillary axis = (kx,ky)*zh[i]
+ *                                                     (reference src/polycap-photon.c:624-627)
+ *   cap2[i] = cap[i]^2
+ *   hexd[i] = sqrt(ext^2 - (ext/2)^2)                 centre-to-edge distance of the outer hexagon
+ *                                                     (reference src/polycap-photon.c:158)
+ * Per-energy constants: complex refractive index n = (1-alfa) + i beta and (1/n)^2
+ * (reference src/polycap-capil.c:497-503), roughness coefficient 1.01358*E*sig_rough (:626).
+ */
+#ifndef PC_PROBLEM_H
+#define PC_PROBLEM_H
+
+#include <cmath>
+#include <complex>
+#include <string>
+#include <vector>
+
+#include "polycap-hip.h"
+#include "pc_device.h"
+
+#define PC_HC     1.23984193E-7
+#define PC_N_AVOG 6.022098e+23
+#define PC_R0     2.8179403227e-13
+
+struct pc_host_tables {
+	std::vector<double> z, cap, zh, cap2, hexd, ext;
+	std::vector<pc_energy_const> ec;
+	pc_params pm;
+};
+
+static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, std::string &err)
+{
+	if (!p || !p->z || !p->cap || !p->ext) { err = "problem/profile arrays must not be NULL"; return PC_HIP_ERR_INVALID; }
+	if (p->nmax < 1) { err = "nmax must be >= 1"; return PC_HIP_ERR_INVALID; }
+	if (p->n_energies < 1 || !p->energies || !p->amu || !p->scatf) { err = "n_energies must be >= 1 with energies/amu/scatf tables"; return PC_HIP_ERR_INVALID; }
+	if (p->n_cap < 1) { err = "n_cap must be >= 1"; return PC_HIP_ERR_INVALID; }
+	const int n = p->nmax + 1;
+	if (!(p->z[0] >= 0.)) { err = "z[0] must be >= 0"; return PC_HIP_ERR_INVALID; }
+	for (int i = 0; i < n; i++) {
+		if (i > 0 && !(p->z[i] > p->z[i-1])) { err = "profile z must be strictly increasing"; return PC_HIP_ERR_INVALID; }
+		if (!(p->cap[i] >= 0.)) { err = "profile cap must be >= 0"; return PC_HIP_ERR_INVALID; }
+	}
+	pc_params &pm = t.pm;
+	pm = pc_params();
+	pm.nmax = p->nmax;
+	pm.n_shells = std::round(std::sqrt(12. * (double)p->n_cap - 3.)/6. - 0.5);   /* src/polycap-photon.c:483 */
+	pm.mono = (pm.n_shells == 0.) ? 1 : 0;
+	pm.n_energies = (int)p->n_energies;
+	pm.literal = 0;
+	pm.hexscale = 2.*PC_COSPI_6*(pm.n_shells + 1);
+	pm.uniform_illum = (p->src_sigx < 0. || p->src_sigy < 0.) ? 1 : 0;
+	pm.generic_src = (p->src_x == p->src_y) ? 0 : 1;
+	pm.d_source = p->d_source; pm.src_x = p->src_x; pm.src_y = p->src_y;
+	pm.src_sigx = p->src_sigx; pm.src_sigy = p->src_sigy;
+	pm.src_shiftx = p->src_shiftx; pm.src_shifty = p->src_shifty;
+	pm.frac_hor_pol = (1. + p->hor_pol)/2.;                                       /* src/polycap-source.c:114 */
+	pm.z_end = p->z[p->nmax];
+	pm.ext_end = p->ext[p->nmax];
+	pm.cap0 = p->cap[0];
+	pm.ext0 = p->ext[0];
+
+	t.z.assign(p->z, p->z + n);
+	t.cap.assign(p->cap, p->cap + n);
+	t.ext.assign(p->ext, p->ext + n);
+	t.zh.resize(n); t.cap2.resize(n); t.hexd.resize(n);
+	double dr2max = 0., capmin = HUGE_VAL, capmax = 0., extmax = 0., ratio = 0.;
+	for (int i = 0; i < n; i++) {
+		double e = p->ext[i], c = p->cap[i];
+		t.zh[i] = e / pm.hexscale;
+		t.cap2[i] = c*c;
+		t.hexd[i] = (e > 0.) ? std::sqrt(e*e - (e/2.)*(e/2.)) : 0.;
+		if (i + 1 < n) {
+			double dr = p->cap[i+1] - c;
+			if (dr*dr > dr2max) dr2max = dr*dr;
+		}
+		if (c < capmin) capmin = c;
+		if (c > capmax) capmax = c;
+		if (std::fabs(e) > extmax) extmax = std::fabs(e);
+		if (e > 0. && c/e > ratio) ratio = c/e;
+		if (!(e > 0.)) ratio = HUGE_VAL;          /* degenerate exterior: keep every hexagon test literal */
+	}
+	double m = std::fmax(1e-6*capmin*capmin, 1e-10*capmax*extmax);
+	pm.adj = 0.25*dr2max + m;
+	pm.bnd_thresh = ratio + 1e-9;
+
+	t.ec.resize(p->n_energies);
+	for (size_t k = 0; k < p->n_energies; k++) {
+		double e = p->energies[k], scatf = p->scatf[k], amu = p->amu[k];
+		pc_energy_const &c = t.ec[k];
+		double alfa = (PC_HC/e)*(PC_HC/e)*((PC_N_AVOG*PC_R0*p->density)/(2*PC_PI)) * scatf;
+		double beta = (PC_HC)/(4.*PC_PI) * (amu/e);
+		std::complex<double> nn(1.0 - alfa, beta);
+		std::complex<double> ninv = 1.0/nn;
+		std::complex<double> ninv2 = ninv*ninv;
+		c.n_re = nn.real(); c.n_im = nn.imag();
+		c.ninv2_re = ninv2.real(); c.ninv2_im = ninv2.imag();
+		c.rough_c = (1.01358e0*e)*p->sig_rough;
+		/* argument checks of polycap_refl_polar, src/polycap-capil.c:463-478 */
+		c.valid = (e >= 1. && e <= 100. && p->density > 0. && scatf >= 0. && amu >= 0.) ? 1. : 0.;
+	}
+	return PC_HIP_OK;
+}
+
+#endif

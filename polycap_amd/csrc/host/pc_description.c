@@ -1,0 +1,243 @@
+/*
+ * pc_description.c -- polycap_description: profile + glass composition + roughness + capillary count.
+ *
+ * Behaviour follows the reference's src/polycap-description.c:
+ *   polycap_read_input_line :24-56, polycap_description_check_weight :58-85,
+ *   polycap_description_new :89-231 (deep copy of the profile, open area, profile validation),
+ *   polycap_description_get_profile :235-238, polycap_description_free :243-253.
+ * Added: the cached HIP context that polycap_photon_launch reuses between launches (pc_ctx_for).
+ */
+#include "pc_private.h"
+
+#include <errno.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+char *polycap_read_input_line(FILE *fptr, polycap_error **error)
+{
+	if (fptr == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_read_input_line: fptr cannot be NULL");
+		return NULL;
+	}
+	size_t cap = 128, len = 0;
+	char *line = malloc(cap);
+	if (line == NULL) {
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_read_input_line: could not allocate memory for strPtr -> %s", strerror(errno));
+		return NULL;
+	}
+	int ch;
+	while ((ch = fgetc(fptr)) != '\n' && ch != EOF) {
+		line[len++] = (char)ch;
+		if (len == cap) {
+			cap += 128;
+			char *grown = realloc(line, cap);
+			if (grown == NULL) {
+				free(line);
+				polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_read_input_line: could not allocate memory for strPtr -> %s", strerror(errno));
+				return NULL;
+			}
+			line = grown;
+		}
+	}
+	line[len++] = '\0';
+	char *fit = realloc(line, len);
+	return fit ? fit : line;
+}
+
+/* weights given in percent (sum > 1) are rescaled to fractions; they must then sum to exactly 1 */
+void polycap_description_check_weight(size_t nelem, double wi[], polycap_error **error)
+{
+	double sum = 0;
+	for (size_t i = 0; i < nelem; i++)
+		sum += wi[i];
+	if (sum > 1.) {
+		sum = 0;
+		for (size_t i = 0; i < nelem; i++) {
+			wi[i] /= 100.0;
+			if (wi[i] < 0.0) {
+				polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_description_check_weight: Polycapillary element weights must be greater than 0.0");
+				return;
+			}
+			sum += wi[i];
+		}
+	}
+	if (sum != 1.)
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_description_check_weight: Polycapillary element weights do not sum to 1.");
+}
+
+static double pc_open_area(const polycap_description *d)
+{
+	double n_cap_temp = (pc_n_shells(d->n_cap)+0.5)*6.;
+	n_cap_temp = (n_cap_temp*n_cap_temp+3)/12;
+	return (d->profile->cap[0]*d->profile->cap[0]*M_PI)*n_cap_temp/(3.*sin(M_PI/3)*d->profile->ext[0]*d->profile->ext[0]);
+}
+
+polycap_description *polycap_description_new(polycap_profile *profile, double sig_rough, int64_t n_cap, unsigned int nelem,
+	int iz[], double wi[], double density, polycap_error **error)
+{
+	if (sig_rough < 0.0) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_description_new: sig_rough must be greater than or equal to zero");
+		return NULL;
+	}
+	if (n_cap <= 1) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_description_new: n_cap must be greater than 1");
+		return NULL;
+	}
+	if (nelem < 1) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_description_new: nelem must be 1 or greater");
+		return NULL;
+	}
+	if (iz == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_description_new: iz cannot be NULL");
+		return NULL;
+	}
+	if (wi == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_description_new: wi cannot be NULL");
+		return NULL;
+	}
+	if (density <= 0.0) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_description_new: density must be greater than 0.0");
+		return NULL;
+	}
+	if (profile == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_description_new: profile cannot be NULL");
+		return NULL;
+	}
+	for (unsigned int i = 0; i < nelem; i++) {
+		if (iz[i] < 1 || iz[i] > 111) {
+			polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_description_new: iz[i] must be greater than 0 and smaller than 111");
+			return NULL;
+		}
+	}
+
+	polycap_description *description = calloc(1, sizeof(polycap_description));
+	if (description != NULL) {
+		description->iz = malloc(sizeof(int)*nelem);
+		description->wi = malloc(sizeof(double)*nelem);
+	}
+	if (description == NULL || description->iz == NULL || description->wi == NULL) {
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_description_new: could not allocate memory for description -> %s", strerror(errno));
+		polycap_description_free(description);
+		return NULL;
+	}
+	description->sig_rough = sig_rough;
+	description->n_cap = n_cap;
+	description->nelem = nelem;
+	description->density = density;
+	memcpy(description->iz, iz, sizeof(int)*nelem);
+	memcpy(description->wi, wi, sizeof(double)*nelem);
+	polycap_description_check_weight(description->nelem, description->wi, error);
+
+	/* deep copy: the caller keeps (and frees) its own profile */
+	description->profile = polycap_profile_new_from_arrays(profile->nmax, profile->ext, profile->cap, profile->z, NULL);
+	if (description->profile == NULL) {
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_description_new: could not allocate memory for description->profile -> %s", strerror(errno));
+		polycap_description_free(description);
+		return NULL;
+	}
+	description->open_area = pc_open_area(description);
+
+	if (polycap_profile_validate(description->profile, description->n_cap, error) != 1) {
+		polycap_clear_error(error);
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_description_new: description->profile is faulty. Some capillary coordinates are outside of the external radius.");
+		polycap_description_free(description);
+		return NULL;
+	}
+	return description;
+}
+
+const polycap_profile *polycap_description_get_profile(polycap_description *description)
+{
+	return description->profile;
+}
+
+void polycap_description_free(polycap_description *description)
+{
+	if (description == NULL)
+		return;
+	pc_ctx_cache_clear(&description->cache);
+	polycap_profile_free(description->profile);
+	free(description->iz);
+	free(description->wi);
+	free(description);
+}
+
+/* ------------------------------------------------------------------ device context cache */
+
+void pc_ctx_cache_clear(pc_ctx_cache *c)
+{
+	if (c == NULL)
+		return;
+	if (c->ctx)
+		pc_hip_ctx_destroy(c->ctx);
+	free(c->energies);
+	memset(c, 0, sizeof(*c));
+}
+
+void pc_set_hip_error(polycap_error **error, const char *caller, int status)
+{
+	enum polycap_error_code code = POLYCAP_ERROR_RUNTIME;
+	if (status == PC_HIP_ERR_INVALID)
+		code = POLYCAP_ERROR_INVALID_ARGUMENT;
+	else if (status == PC_HIP_ERR_MEMORY)
+		code = POLYCAP_ERROR_MEMORY;
+	polycap_set_error(error, code, "%s: GPU trace path failed (%d): %s", caller, status, pc_hip_last_error());
+}
+
+/* Returns the HIP context for (description, energies[, source]); rebuilt only when one of them changed.
+ * The device is POLYCAP_HIP_DEVICE (default 0).  There is no CPU fallback: failure is reported to the caller. */
+pc_hip_ctx *pc_ctx_for(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
+	const polycap_source *source, const char *caller, polycap_error **error)
+{
+	double src[8] = {1., 1., 1., 0., 0., 0., 0., 0.};
+	if (source != NULL) {
+		src[0] = source->d_source; src[1] = source->src_x; src[2] = source->src_y; src[3] = source->src_sigx;
+		src[4] = source->src_sigy; src[5] = source->src_shiftx; src[6] = source->src_shifty; src[7] = source->hor_pol;
+	}
+	if (c->ctx != NULL && c->n_energies == n_energies && memcmp(c->energies, energies, sizeof(double)*n_energies) == 0 &&
+	    c->has_source == (source != NULL) && memcmp(c->src, src, sizeof(src)) == 0)
+		return c->ctx;
+	pc_ctx_cache_clear(c);
+
+	double *amu = malloc(sizeof(double)*n_energies);
+	double *scatf = malloc(sizeof(double)*n_energies);
+	c->energies = malloc(sizeof(double)*n_energies);
+	if (amu == NULL || scatf == NULL || c->energies == NULL) {
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "%s: could not allocate memory for optical constants -> %s", caller, strerror(errno));
+		free(amu); free(scatf);
+		pc_ctx_cache_clear(c);
+		return NULL;
+	}
+	int synthetic = 0;
+	if (pc_optconst_scatf(description->nelem, description->iz, description->wi, description->density,
+	                      n_energies, energies, amu, scatf, &synthetic, error) != 0) {
+		free(amu); free(scatf);
+		pc_ctx_cache_clear(c);
+		return NULL;
+	}
+	pc_hip_problem p;
+	memset(&p, 0, sizeof(p));
+	p.nmax = description->profile->nmax;
+	p.z = description->profile->z; p.cap = description->profile->cap; p.ext = description->profile->ext;
+	p.sig_rough = description->sig_rough; p.n_cap = description->n_cap; p.density = description->density;
+	p.n_energies = n_energies; p.energies = energies; p.amu = amu; p.scatf = scatf;
+	p.d_source = src[0]; p.src_x = src[1]; p.src_y = src[2]; p.src_sigx = src[3]; p.src_sigy = src[4];
+	p.src_shiftx = src[5]; p.src_shifty = src[6]; p.hor_pol = src[7];
+	int device = 0;
+	const char *env = getenv("POLYCAP_HIP_DEVICE");
+	if (env != NULL && *env != '\0')
+		device = atoi(env);
+	int status = pc_hip_ctx_create(&p, device, &c->ctx);
+	free(amu); free(scatf);
+	if (status != PC_HIP_OK) {
+		pc_set_hip_error(error, caller, status);
+		pc_ctx_cache_clear(c);
+		return NULL;
+	}
+	c->n_energies = n_energies;
+	memcpy(c->energies, energies, sizeof(double)*n_energies);
+	c->has_source = (source != NULL);
+	memcpy(c->src, src, sizeof(src));
+	return c->ctx;
+}

@@ -1,0 +1,133 @@
+/*
+ * pc_private.h -- internal structures of libpolycap's host side (C11).
+ *
+ * Field meaning follows the reference's src/polycap-private.h:88-181 (profile, description, source,
+ * photon, transmission_efficiencies, images); the HIP context handles are additions of this build.
+ */
+#ifndef PC_PRIVATE_H
+#define PC_PRIVATE_H
+
+#include "polycap.h"
+
+#include <stdio.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+#define PC_COSPI_6 0.86602540378443864676
+
+struct _polycap_profile {
+	int nmax;          /* arrays hold nmax+1 points */
+	double *z;
+	double *cap;
+	double *ext;
+};
+
+/* cached device context for one (description, energy grid, source) combination */
+typedef struct {
+	pc_hip_ctx *ctx;
+	size_t n_energies;
+	double *energies;
+	int has_source;
+	double src[8];
+} pc_ctx_cache;
+
+struct _polycap_description {
+	double sig_rough;
+	int64_t n_cap;
+	double open_area;
+	unsigned int nelem;
+	int *iz;
+	double *wi;
+	double density;
+	polycap_profile *profile;
+	pc_ctx_cache cache;   /* used by polycap_photon_launch */
+};
+
+struct _polycap_rng {
+	uint64_t seed;     /* Philox key */
+	uint64_t counter;  /* next photon index of this stream */
+};
+
+struct _polycap_source {
+	polycap_description *description;
+	polycap_rng *rng;
+	double d_source;
+	double src_x;
+	double src_y;
+	double src_sigx;
+	double src_sigy;
+	double src_shiftx;
+	double src_shifty;
+	double hor_pol;
+	size_t n_energies;
+	double *energies;
+	pc_ctx_cache cache;   /* used by get_photon / get_transmission_efficiencies */
+	uint64_t run_index;   /* successive get_transmission_efficiencies calls use distinct Philox keys */
+};
+
+struct _polycap_photon {
+	polycap_description *description;
+	polycap_leak **extleak;
+	polycap_leak **intleak;
+	int64_t n_extleak;
+	int64_t n_intleak;
+	polycap_vector3 start_coords;
+	polycap_vector3 start_direction;
+	polycap_vector3 start_electric_vector;
+	polycap_vector3 exit_coords;
+	polycap_vector3 exit_direction;
+	polycap_vector3 exit_electric_vector;
+	polycap_vector3 src_start_coords;
+	size_t n_energies;
+	double *energies;
+	double *weight;
+	double *amu;
+	double *scatf;
+	int64_t i_refl;
+	double d_travel;
+};
+
+struct _polycap_images {
+	int64_t i_start;
+	int64_t i_exit;
+	double *src_start_coords[2];
+	double *pc_start_coords[2];
+	double *pc_start_dir[2];
+	double *pc_start_elecv[2];
+	double *pc_exit_coords[3];
+	double *pc_exit_dir[2];
+	double *pc_exit_elecv[2];
+	int64_t *pc_exit_nrefl;
+	double *pc_exit_dtravel;
+	double *exit_coord_weights;
+	int64_t i_extleak;
+	int64_t i_intleak;
+};
+
+struct _polycap_transmission_efficiencies {
+	size_t n_energies;
+	double *energies;
+	double *efficiencies;
+	struct _polycap_images *images;
+	polycap_source *source;
+};
+
+/* internal helpers */
+char *polycap_read_input_line(FILE *fptr, polycap_error **error);
+void polycap_description_check_weight(size_t nelem, double wi[], polycap_error **error);
+double pc_n_shells(int64_t n_cap);
+int polycap_photon_within_pc_boundary(double polycap_radius, polycap_vector3 photon_coord, polycap_error **error);
+
+/* optical constants (what polycap_photon_scatf computes in the reference, src/polycap-photon.c:22-94) */
+POLYCAP_EXTERN int pc_optconst_scatf(unsigned int nelem, const int *iz, const double *wi, double density,
+	size_t n_energies, const double *energies, double *amu, double *scatf, int *synthetic, polycap_error **error);
+POLYCAP_EXTERN const char *pc_optconst_provider(void);
+
+/* device context management */
+void pc_ctx_cache_clear(pc_ctx_cache *c);
+pc_hip_ctx *pc_ctx_for(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
+	const polycap_source *source, const char *caller, polycap_error **error);
+void pc_set_hip_error(polycap_error **error, const char *caller, int status);
+
+#endif

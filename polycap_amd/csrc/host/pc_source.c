@@ -1,0 +1,500 @@
+/*
+ * pc_source.c -- polycap_source: X-ray source + optic + energy grid, and the photon-loop driver.
+ *
+ * API and error behaviour of the reference's src/polycap-source.c:
+ *   polycap_source_new :147-225, polycap_source_new_from_file :228-445 (legacy positional .inp deck),
+ *   polycap_source_get_photon :23-144, polycap_source_get_transmission_efficiencies :448-1087,
+ *   polycap_source_free / polycap_source_get_description :1090-1109.
+ * The photon loop (the reference's OpenMP region :697-1049) runs on the GPU: this file only validates,
+ * uploads the problem once, enqueues pc_hip_transmission_run for the n_photons exit-photon slots and copies
+ * the image planes back.  Photon streams are Philox(seed, slot, attempt): the reference seeds one mt19937 per
+ * OpenMP thread from /dev/urandom, so its runs are not reproducible; here POLYCAP_SEED fixes the key.
+ */
+#define _GNU_SOURCE
+#include "pc_private.h"
+
+#include <errno.h>
+#include <inttypes.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+polycap_source *polycap_source_new(polycap_description *description, double d_source, double src_x, double src_y,
+	double src_sigx, double src_sigy, double src_shiftx, double src_shifty, double hor_pol,
+	size_t n_energies, double *energies, polycap_error **error)
+{
+	if (description == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_new: description cannot be NULL");
+		return NULL;
+	}
+	if (d_source <= 0.) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_new: d_source must be greater than 0");
+		return NULL;
+	}
+	if (src_x <= 0.) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_new: src_x must be greater than 0");
+		return NULL;
+	}
+	if (src_y <= 0.) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_new: src_y must be greater than 0");
+		return NULL;
+	}
+	if (fabs(hor_pol) > 1.) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_new: hor_pol must be greater than or equal to -1 and smaller than or equal to 1");
+		return NULL;
+	}
+	if (n_energies <= 0.) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_new: n_energies must be greater than 0");
+		return NULL;
+	}
+	if (energies == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_new: energies cannot be NULL");
+		return NULL;
+	}
+	for (size_t i = 0; i < n_energies; i++) {
+		if (energies[i] < 1. || energies[i] > 100.) {
+			polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_new: energies must be greater than 1 and smaller than 100");
+			return NULL;
+		}
+	}
+	if (polycap_profile_validate(description->profile, description->n_cap, error) != 1) {
+		polycap_clear_error(error);
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_new: description->profile is faulty. Some capillary coordinates are outside of the external radius.");
+		return NULL;
+	}
+
+	polycap_source *source = calloc(1, sizeof(polycap_source));
+	if (source != NULL)
+		source->energies = malloc(sizeof(double)*n_energies);
+	if (source == NULL || source->energies == NULL) {
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_source_new: could not allocate memory for source -> %s", strerror(errno));
+		polycap_source_free(source);
+		return NULL;
+	}
+	source->d_source = d_source;
+	source->src_x = src_x;
+	source->src_y = src_y;
+	source->src_sigx = src_sigx;
+	source->src_sigy = src_sigy;
+	source->src_shiftx = src_shiftx;
+	source->src_shifty = src_shifty;
+	source->hor_pol = hor_pol;
+	source->n_energies = n_energies;
+	memcpy(source->energies, energies, sizeof(double)*n_energies);
+	source->rng = polycap_rng_new();
+	/* the source keeps its own deep copy of the description (tests free the original right away) */
+	source->description = polycap_description_new(description->profile, description->sig_rough, description->n_cap,
+		description->nelem, description->iz, description->wi, description->density, NULL);
+	if (source->description == NULL) {
+		polycap_clear_error(error);
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_new: description->profile is faulty. Some capillary coordinates are outside of the external radius.");
+		polycap_source_free(source);
+		return NULL;
+	}
+	return source;
+}
+
+/* opens `name`; a relative name that does not exist in the working directory is retried next to the .inp deck */
+static char *pc_resolve_near(const char *deck, const char *name)
+{
+	FILE *probe = fopen(name, "r");
+	if (probe != NULL) {
+		fclose(probe);
+		return strdup(name);
+	}
+	const char *slash = strrchr(deck, '/');
+	if (name[0] == '/' || slash == NULL)
+		return strdup(name);
+	size_t dirlen = (size_t)(slash - deck) + 1;
+	char *joined = malloc(dirlen + strlen(name) + 1);
+	if (joined == NULL)
+		return NULL;
+	memcpy(joined, deck, dirlen);
+	strcpy(joined + dirlen, name);
+	return joined;
+}
+
+polycap_source *polycap_source_new_from_file(const char *filename, polycap_error **error)
+{
+	if (filename == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_new_from_file: filename cannot be NULL");
+		return NULL;
+	}
+	polycap_description *description = calloc(1, sizeof(polycap_description));
+	polycap_source *source = calloc(1, sizeof(polycap_source));
+	if (description == NULL || source == NULL) {
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_source_new_from_file: could not allocate memory for source -> %s", strerror(errno));
+		free(description);
+		free(source);
+		return NULL;
+	}
+	source->description = description;
+	source->rng = polycap_rng_new();
+
+	FILE *fptr = fopen(filename, "r");
+	if (fptr == NULL) {
+		polycap_set_error(error, POLYCAP_ERROR_IO, "polycap_source_new_from_file: could not open %s -> %s", filename, strerror(errno));
+		polycap_source_free(source);
+		return NULL;
+	}
+
+	/* positional deck, reference src/polycap-source.c:273-369 */
+	double e_start = 0., e_final = 0., delta_e = 1.;
+	int nphotons = 0, type = 0;
+	int ok = 1;
+	ok &= fscanf(fptr, "%lf", &description->sig_rough) == 1;
+	ok &= fscanf(fptr, "%lf", &source->d_source) == 1;
+	ok &= fscanf(fptr, "%lf %lf", &source->src_x, &source->src_y) == 2;
+	ok &= fscanf(fptr, "%lf %lf", &source->src_sigx, &source->src_sigy) == 2;
+	ok &= fscanf(fptr, "%lf %lf", &source->src_shiftx, &source->src_shifty) == 2;
+	ok &= fscanf(fptr, "%lf", &source->hor_pol) == 1;
+	ok &= fscanf(fptr, "%u", &description->nelem) == 1;
+	if (!ok || description->nelem < 1 || description->nelem > 111) {
+		fclose(fptr);
+		polycap_set_error(error, POLYCAP_ERROR_IO, "polycap_source_new_from_file: could not read the source/composition header of %s", filename);
+		polycap_source_free(source);
+		return NULL;
+	}
+	description->iz = malloc(sizeof(int)*description->nelem);
+	description->wi = malloc(sizeof(double)*description->nelem);
+	if (description->iz == NULL || description->wi == NULL) {
+		fclose(fptr);
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_source_new_from_file: could not allocate memory for description->iz -> %s", strerror(errno));
+		polycap_source_free(source);
+		return NULL;
+	}
+	for (unsigned int i = 0; i < description->nelem; i++) {
+		ok &= fscanf(fptr, "%d %lf", &description->iz[i], &description->wi[i]) == 2;
+		description->wi[i] /= 100.0;
+	}
+	ok &= fscanf(fptr, "%lf", &description->density) == 1;
+	ok &= fscanf(fptr, "%lf %lf %lf", &e_start, &e_final, &delta_e) == 3;
+	if (!ok) {
+		fclose(fptr);
+		polycap_set_error(error, POLYCAP_ERROR_IO, "polycap_source_new_from_file: could not read composition/energies from %s", filename);
+		polycap_source_free(source);
+		return NULL;
+	}
+	source->n_energies = (size_t)((e_final-e_start)/delta_e + 1);
+	if (source->n_energies <= 0. || source->n_energies > 100000000u) {
+		fclose(fptr);
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_new_from_file: source->n_energies must be greater than 0");
+		polycap_source_free(source);
+		return NULL;
+	}
+	source->energies = malloc(sizeof(double)*source->n_energies);
+	if (source->energies == NULL) {
+		fclose(fptr);
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_source_new_from_file: could not allocate memory for source->energies -> %s", strerror(errno));
+		polycap_source_free(source);
+		return NULL;
+	}
+	for (size_t i = 0; i < source->n_energies; i++)
+		source->energies[i] = e_start + i*delta_e;
+	ok &= fscanf(fptr, "%d", &nphotons) == 1;   /* read and ignored, as in the reference (:343) */
+	ok &= fscanf(fptr, "%d", &type) == 1;
+	if (ok && (type == 0 || type == 1 || type == 2)) {
+		double length, rad_ext_upstream, rad_ext_downstream, rad_int_upstream, rad_int_downstream, focal_dist_upstream, focal_dist_downstream;
+		if (fscanf(fptr, "%lf %lf %lf %lf %lf %lf %lf", &length, &rad_ext_upstream, &rad_ext_downstream, &rad_int_upstream,
+		           &rad_int_downstream, &focal_dist_upstream, &focal_dist_downstream) != 7) {
+			fclose(fptr);
+			polycap_set_error(error, POLYCAP_ERROR_IO, "polycap_source_new_from_file: could not read the profile shape from %s", filename);
+			polycap_source_free(source);
+			return NULL;
+		}
+		description->profile = polycap_profile_new((polycap_profile_type)type, length, rad_ext_upstream, rad_ext_downstream,
+			rad_int_upstream, rad_int_downstream, focal_dist_upstream, focal_dist_downstream, error);
+	} else if (ok) {
+		fgetc(fptr); /* rest of the "type" line */
+		char *names[3] = { NULL, NULL, NULL };
+		for (int k = 0; k < 3; k++) {
+			char *raw = polycap_read_input_line(fptr, NULL);
+			names[k] = raw ? pc_resolve_near(filename, raw) : NULL;
+			free(raw);
+		}
+		if (names[0] && names[1] && names[2])
+			description->profile = polycap_profile_new_from_file(names[0], names[1], names[2], error);
+		for (int k = 0; k < 3; k++)
+			free(names[k]);
+	}
+	if (!ok || description->profile == NULL) {
+		fclose(fptr);
+		if (error != NULL && *error == NULL)
+			polycap_set_error(error, POLYCAP_ERROR_IO, "polycap_source_new_from_file: could not read the profile section of %s", filename);
+		polycap_source_free(source);
+		return NULL;
+	}
+	if (fscanf(fptr, "%" SCNd64, &description->n_cap) != 1)
+		description->n_cap = 0;
+	fclose(fptr);
+
+	polycap_description_check_weight(description->nelem, description->wi, error);
+
+	double n_cap = (pc_n_shells(description->n_cap)+0.5)*6.;
+	n_cap = (n_cap*n_cap+3)/12;
+	description->open_area = (description->profile->cap[0]*description->profile->cap[0]*M_PI)*n_cap/(3.*sin(M_PI/3)*description->profile->ext[0]*description->profile->ext[0]);
+
+	/* sanity checks of the reference, :380-437 */
+	const char *problem = NULL;
+	if (source->d_source < 0.0) problem = "polycap_source_new_from_file: source_temp->d_source must be greater than 0.0";
+	else if (source->src_x < 0.0) problem = "polycap_source_new_from_file: source_temp->src_x must be greater than 0.0";
+	else if (source->src_y < 0.0) problem = "polycap_source_new_from_file: source_temp->src_y must be greater than 0.0";
+	else if (description->n_cap < 1) problem = "polycap_source_new_from_file: description->n_cap must be greater than 1";
+	else if (description->open_area < 0 || description->open_area > 1) problem = "polycap_source_new_from_file: description->open_area must be greater than 0 and less than 1";
+	else if (description->density < 0.0) problem = "polycap_source_new_from_file: description->density must be greater than 0.0";
+	for (size_t i = 0; problem == NULL && i < source->n_energies; i++)
+		if (source->energies[i] < 1. || source->energies[i] > 100.)
+			problem = "polycap_source_new_from_file: source->energies must be greater than 1 and smaller than 100";
+	for (unsigned int i = 0; problem == NULL && i < description->nelem; i++)
+		if (description->iz[i] < 1 || description->iz[i] > 94)
+			problem = "polycap_source_new_from_file: description->iz[i] must be greater than 0 and less than 94";
+	if (problem != NULL) {
+		polycap_clear_error(error);
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, problem);
+		polycap_source_free(source);
+		return NULL;
+	}
+	if (polycap_profile_validate(description->profile, description->n_cap, error) != 1) {
+		polycap_clear_error(error);
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_new_from_file: description->profile is faulty. Some capillary coordinates are outside of the external radius.");
+		polycap_source_free(source);
+		return NULL;
+	}
+	return source;
+}
+
+/* One photon of the stream (rng->seed, photon index rng->counter++), sampled by the device sampler. */
+polycap_photon *polycap_source_get_photon(polycap_source *source, polycap_rng *rng, polycap_error **error)
+{
+	if (source == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_photon: source cannot be NULL");
+		return NULL;
+	}
+	polycap_description *description = source->description;
+	if (description == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_photon: description cannot be NULL");
+		return NULL;
+	}
+	if (rng == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_photon: rng cannot be NULL");
+		return NULL;
+	}
+	pc_hip_ctx *ctx = pc_ctx_for(&source->cache, description, source->n_energies, source->energies, source, "polycap_source_get_photon", error);
+	if (ctx == NULL)
+		return NULL;
+	int64_t slot = (int64_t)(rng->counter++ & 0x7fffffffffffffffull);
+	uint32_t attempt = 0;
+	double out[12];
+	int status = pc_hip_sample_photons(ctx, rng->seed, 1, &slot, &attempt, out);
+	if (status != PC_HIP_OK) {
+		pc_set_hip_error(error, "polycap_source_get_photon", status);
+		return NULL;
+	}
+	polycap_vector3 start_coords = { out[0], out[1], out[2] };
+	polycap_vector3 start_direction = { out[3], out[4], out[5] };
+	polycap_vector3 start_electric_vector = { out[6], out[7], out[8] };
+	polycap_photon *photon = polycap_photon_new(description, start_coords, start_direction, start_electric_vector, error);
+	if (photon == NULL)
+		return NULL;
+	photon->src_start_coords.x = out[9];
+	photon->src_start_coords.y = out[10];
+	photon->src_start_coords.z = 0.;
+	return photon;
+}
+
+static uint64_t pc_env_u64(const char *name, uint64_t fallback, int *present)
+{
+	const char *env = getenv(name);
+	if (present) *present = 0;
+	if (env == NULL || *env == '\0')
+		return fallback;
+	char *end = NULL;
+	unsigned long long v = strtoull(env, &end, 0);
+	if (end == env)
+		return fallback;
+	if (present) *present = 1;
+	return (uint64_t)v;
+}
+
+polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(polycap_source *source, int max_threads, int n_photons,
+	bool leak_calc, polycap_progress_monitor *progress_monitor, polycap_error **error)
+{
+	(void)max_threads; /* host-thread cap in the reference (:492-493); the photon loop runs on the GPU here */
+	if (source == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_transmission_efficiencies: source cannot be NULL");
+		return NULL;
+	}
+	if (progress_monitor != NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_transmission_efficiencies: progress_monitor must be NULL as polycap_progress_monitor currently has no implementation");
+		return NULL;
+	}
+	polycap_description *description = source->description;
+	if (description == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_transmission_efficiencies: description cannot be NULL");
+		return NULL;
+	}
+	if (source->n_energies < 1) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_transmission_efficiencies: source->n_energies must be greater than or equal to 1");
+		return NULL;
+	}
+	if (source->energies == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_transmission_efficiencies: source->energies cannot be NULL");
+		return NULL;
+	}
+	for (size_t i = 0; i < source->n_energies; i++) {
+		if (source->energies[i] < 1. || source->energies[i] > 100.) {
+			polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_transmission_efficiencies: source->energies[i] must be greater than 1 and less than 100");
+			return NULL;
+		}
+	}
+	if (n_photons < 1) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_transmission_efficiencies: n_photons must be greater than 1");
+		return NULL;
+	}
+	if (leak_calc) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_UNSUPPORTED, "polycap_source_get_transmission_efficiencies: leak_calc=true (halo photons) is not implemented in the MI355X build");
+		return NULL;
+	}
+
+	const size_t ne = source->n_energies;
+	const size_t np = (size_t)n_photons;
+	polycap_transmission_efficiencies *eff = calloc(1, sizeof(*eff));
+	struct _polycap_images *img = calloc(1, sizeof(*img));
+	double *sum_weights = malloc(sizeof(double)*ne);
+	int alloc_ok = (eff != NULL && img != NULL && sum_weights != NULL);
+	if (alloc_ok) {
+		eff->images = img;
+		img = NULL;
+		eff->energies = malloc(sizeof(double)*ne);
+		eff->efficiencies = malloc(sizeof(double)*ne);
+		double **planes[] = { &eff->images->src_start_coords[0], &eff->images->src_start_coords[1],
+			&eff->images->pc_start_coords[0], &eff->images->pc_start_coords[1],
+			&eff->images->pc_start_dir[0], &eff->images->pc_start_dir[1],
+			&eff->images->pc_start_elecv[0], &eff->images->pc_start_elecv[1],
+			&eff->images->pc_exit_coords[0], &eff->images->pc_exit_coords[1], &eff->images->pc_exit_coords[2],
+			&eff->images->pc_exit_dir[0], &eff->images->pc_exit_dir[1],
+			&eff->images->pc_exit_elecv[0], &eff->images->pc_exit_elecv[1], &eff->images->pc_exit_dtravel };
+		alloc_ok = (eff->energies != NULL && eff->efficiencies != NULL);
+		for (size_t k = 0; k < sizeof(planes)/sizeof(planes[0]); k++) {
+			*planes[k] = malloc(sizeof(double)*np);
+			alloc_ok = alloc_ok && (*planes[k] != NULL);
+		}
+		eff->images->pc_exit_nrefl = malloc(sizeof(int64_t)*np);
+		eff->images->exit_coord_weights = malloc(sizeof(double)*np*ne);
+		alloc_ok = alloc_ok && eff->images->pc_exit_nrefl != NULL && eff->images->exit_coord_weights != NULL;
+	}
+	if (!alloc_ok) {
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_source_get_transmission_efficiencies: could not allocate memory for efficiencies -> %s", strerror(errno));
+		free(img);
+		free(sum_weights);
+		polycap_transmission_efficiencies_free(eff);
+		return NULL;
+	}
+	eff->source = source;
+	eff->n_energies = ne;
+
+	pc_hip_ctx *ctx = pc_ctx_for(&source->cache, description, ne, source->energies, source, "polycap_source_get_transmission_efficiencies", error);
+	if (ctx == NULL) {
+		free(sum_weights);
+		polycap_transmission_efficiencies_free(eff);
+		return NULL;
+	}
+	int have_seed = 0;
+	uint64_t seed = pc_env_u64("POLYCAP_SEED", 0, &have_seed);
+	if (!have_seed)
+		seed = source->rng->seed + 0x9E3779B97F4A7C15ull * source->run_index;
+	source->run_index++;
+	uint32_t max_attempts = (uint32_t)pc_env_u64("POLYCAP_MAX_ATTEMPTS", 1u << 20, NULL);
+
+	int64_t counters[6] = {0, 0, 0, 0, 0, 0};
+	int status = pc_hip_transmission_run(ctx, seed, 0, n_photons, max_attempts, 1);
+	if (status == PC_HIP_OK)
+		status = pc_hip_transmission_wait(ctx, NULL);
+	if (status == PC_HIP_OK)
+		status = pc_hip_transmission_totals(ctx, sum_weights, counters, NULL);
+	if (status == PC_HIP_OK) {
+		pc_hip_images dst;
+		memset(&dst, 0, sizeof(dst));
+		for (int k = 0; k < 2; k++) {
+			dst.src_start_coords[k] = eff->images->src_start_coords[k];
+			dst.pc_start_coords[k] = eff->images->pc_start_coords[k];
+			dst.pc_start_dir[k] = eff->images->pc_start_dir[k];
+			dst.pc_start_elecv[k] = eff->images->pc_start_elecv[k];
+			dst.pc_exit_dir[k] = eff->images->pc_exit_dir[k];
+			dst.pc_exit_elecv[k] = eff->images->pc_exit_elecv[k];
+		}
+		for (int k = 0; k < 3; k++)
+			dst.pc_exit_coords[k] = eff->images->pc_exit_coords[k];
+		dst.pc_exit_nrefl = eff->images->pc_exit_nrefl;
+		dst.pc_exit_dtravel = eff->images->pc_exit_dtravel;
+		dst.exit_coord_weights = eff->images->exit_coord_weights;
+		status = pc_hip_transmission_images(ctx, 0, n_photons, &dst);
+	}
+	if (status != PC_HIP_OK) {
+		pc_set_hip_error(error, "polycap_source_get_transmission_efficiencies", status);
+		free(sum_weights);
+		polycap_transmission_efficiencies_free(eff);
+		return NULL;
+	}
+
+	/* totals, summary lines and efficiency formula of the reference, :1055-1076 */
+	int64_t sum_iexit = counters[0], sum_not_entered = counters[1], sum_not_transmitted = counters[2], sum_irefl = counters[3];
+	printf("Average number of reflections: %lf, Simulated photons: %" PRId64 "\n", (double)sum_irefl/n_photons, sum_iexit+sum_not_entered+sum_not_transmitted);
+	printf("Open area Calculated: %lf, Simulated: %lf\n",
+		((pc_n_shells(description->n_cap)+0.5)*6.)*((pc_n_shells(description->n_cap)+0.5)*6.)/12.*(description->profile->cap[0]*description->profile->cap[0]*M_PI)/(3.*sin(M_PI/3)*description->profile->ext[0]*description->profile->ext[0]),
+		(double)(sum_iexit+sum_not_transmitted)/(sum_iexit+sum_not_entered+sum_not_transmitted));
+	printf("iexit: %" PRId64 ", no enter: %" PRId64 ", no trans: %" PRId64 "\n", sum_iexit, sum_not_entered, sum_not_transmitted);
+
+	description->open_area = (double)(sum_iexit+sum_not_transmitted)/(sum_iexit+sum_not_entered+sum_not_transmitted);
+	eff->images->i_start = sum_iexit+sum_not_entered+sum_not_transmitted;
+	eff->images->i_exit = sum_iexit;
+	for (size_t i = 0; i < ne; i++) {
+		eff->energies[i] = source->energies[i];
+		eff->efficiencies[i] = (sum_weights[i] / ((double)sum_iexit+(double)sum_not_transmitted)) * description->open_area;
+	}
+	free(sum_weights);
+	return eff;
+}
+
+void polycap_source_free(polycap_source *source)
+{
+	if (source == NULL)
+		return;
+	pc_ctx_cache_clear(&source->cache);
+	polycap_description_free(source->description);
+	polycap_rng_free(source->rng);
+	free(source->energies);
+	free(source);
+}
+
+const polycap_description *polycap_source_get_description(polycap_source *source)
+{
+	return source->description;
+}
+
+/* Fills *p with the plain-array view of `source` (pointers borrowed from the source, valid while it lives);
+ * amu/scatf are computed by the optical-constants provider into caller-owned arrays of n_energies doubles.
+ * Used by the Python layer to build problems from .inp decks with the one C parser. Returns 0 on success. */
+POLYCAP_EXTERN int pc_source_problem(polycap_source *source, pc_hip_problem *p, double *amu, double *scatf, int *synthetic, polycap_error **error);
+int pc_source_problem(polycap_source *source, pc_hip_problem *p, double *amu, double *scatf, int *synthetic, polycap_error **error)
+{
+	if (source == NULL || p == NULL || source->description == NULL || source->description->profile == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "pc_source_problem: source and p cannot be NULL");
+		return -1;
+	}
+	polycap_description *d = source->description;
+	memset(p, 0, sizeof(*p));
+	p->nmax = d->profile->nmax;
+	p->z = d->profile->z; p->cap = d->profile->cap; p->ext = d->profile->ext;
+	p->sig_rough = d->sig_rough; p->n_cap = d->n_cap; p->density = d->density;
+	p->n_energies = source->n_energies; p->energies = source->energies;
+	p->d_source = source->d_source; p->src_x = source->src_x; p->src_y = source->src_y;
+	p->src_sigx = source->src_sigx; p->src_sigy = source->src_sigy;
+	p->src_shiftx = source->src_shiftx; p->src_shifty = source->src_shifty; p->hor_pol = source->hor_pol;
+	if (amu != NULL && scatf != NULL) {
+		if (pc_optconst_scatf(d->nelem, d->iz, d->wi, d->density, source->n_energies, source->energies, amu, scatf, synthetic, error) != 0)
+			return -1;
+		p->amu = amu; p->scatf = scatf;
+	}
+	return 0;
+}

@@ -1,0 +1,219 @@
+/*
+ * pc_transeff.c -- polycap_transmission_efficiencies: the result object of the photon loop.
+ *
+ * Layout and getters follow the reference's src/polycap-transmission-efficiencies.c:782-1172:
+ * SoA image planes indexed by exit-photon slot, exit_coord_weights row-major by photon; getters hand out
+ * malloc'd copies (caller frees with polycap_free).  Leak planes are absent (leak_calc is unsupported), so the
+ * leak getters report "no leak events" exactly as the reference does for an empty list.
+ * The HDF5 writer (reference :38-780) is outside this round's scope and reports POLYCAP_ERROR_UNSUPPORTED.
+ */
+#include "pc_private.h"
+
+#include <errno.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static void pc_images_free(struct _polycap_images *images)
+{
+	if (images == NULL)
+		return;
+	for (int k = 0; k < 2; k++) {
+		free(images->src_start_coords[k]);
+		free(images->pc_start_coords[k]);
+		free(images->pc_start_dir[k]);
+		free(images->pc_start_elecv[k]);
+		free(images->pc_exit_dir[k]);
+		free(images->pc_exit_elecv[k]);
+	}
+	for (int k = 0; k < 3; k++)
+		free(images->pc_exit_coords[k]);
+	free(images->pc_exit_nrefl);
+	free(images->pc_exit_dtravel);
+	free(images->exit_coord_weights);
+	free(images);
+}
+
+void polycap_transmission_efficiencies_free(polycap_transmission_efficiencies *efficiencies)
+{
+	if (efficiencies == NULL)
+		return;
+	free(efficiencies->energies);
+	free(efficiencies->efficiencies);
+	pc_images_free(efficiencies->images);
+	free(efficiencies);
+}
+
+bool polycap_transmission_efficiencies_get_data(polycap_transmission_efficiencies *efficiencies, size_t *n_energies,
+	double **energies_arr, double **efficiencies_arr, polycap_error **error)
+{
+	if (efficiencies == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_transmission_efficiencies_get_data: efficiencies cannot be NULL");
+		return false;
+	}
+	if (n_energies)
+		*n_energies = efficiencies->n_energies;
+	if (energies_arr) {
+		*energies_arr = malloc(sizeof(double) * efficiencies->n_energies);
+		if (*energies_arr == NULL) {
+			polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_transmission_efficiencies_get_data: could not allocate memory -> %s", strerror(errno));
+			return false;
+		}
+		memcpy(*energies_arr, efficiencies->energies, sizeof(double) * efficiencies->n_energies);
+	}
+	if (efficiencies_arr) {
+		*efficiencies_arr = malloc(sizeof(double) * efficiencies->n_energies);
+		if (*efficiencies_arr == NULL) {
+			polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_transmission_efficiencies_get_data: could not allocate memory -> %s", strerror(errno));
+			return false;
+		}
+		memcpy(*efficiencies_arr, efficiencies->efficiencies, sizeof(double) * efficiencies->n_energies);
+	}
+	return true;
+}
+
+/* (x, y, sqrt(1 - x^2 - y^2)) from the two stored components, as the reference rebuilds unit vectors (:841-848) */
+static polycap_vector3 pc_unit_from_xy(double x, double y)
+{
+	polycap_vector3 v = { x, y, sqrt(1. - x*x - y*y) };
+	return v;
+}
+
+bool polycap_transmission_efficiencies_get_start_data(polycap_transmission_efficiencies *efficiencies, int64_t *n_start, int64_t *n_exit,
+	polycap_vector3 **start_coords, polycap_vector3 **start_direction, polycap_vector3 **start_elecv, polycap_vector3 **src_start_coords,
+	polycap_error **error)
+{
+	if (efficiencies == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_start_data: efficiencies cannot be NULL");
+		return false;
+	}
+	const struct _polycap_images *im = efficiencies->images;
+	if (im == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_start_data: source->images cannot be NULL");
+		return false;
+	}
+	*n_start = im->i_start;
+	if (im->i_start == 0) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_start_data: no photon start events in efficiencies");
+		return false;
+	}
+	*n_exit = im->i_exit;
+	if (im->i_exit == 0) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_start_data: no photon exit events in efficiencies");
+		return false;
+	}
+	const size_t n = (size_t)im->i_exit;
+	*start_coords = malloc(sizeof(polycap_vector3) * n);
+	*start_direction = malloc(sizeof(polycap_vector3) * n);
+	*start_elecv = malloc(sizeof(polycap_vector3) * n);
+	*src_start_coords = malloc(sizeof(polycap_vector3) * n);
+	if (*start_coords == NULL || *start_direction == NULL || *start_elecv == NULL || *src_start_coords == NULL) {
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_source_get_start_data: could not allocate memory for start data -> %s", strerror(errno));
+		return false;
+	}
+	for (size_t i = 0; i < n; i++) {
+		(*start_coords)[i].x = im->pc_start_coords[0][i];
+		(*start_coords)[i].y = im->pc_start_coords[1][i];
+		(*start_coords)[i].z = 0.;
+		(*start_direction)[i] = pc_unit_from_xy(im->pc_start_dir[0][i], im->pc_start_dir[1][i]);
+		(*start_elecv)[i] = pc_unit_from_xy(im->pc_start_elecv[0][i], im->pc_start_elecv[1][i]);
+		(*src_start_coords)[i].x = im->src_start_coords[0][i];
+		(*src_start_coords)[i].y = im->src_start_coords[1][i];
+		(*src_start_coords)[i].z = 0.;
+	}
+	return true;
+}
+
+bool polycap_transmission_efficiencies_get_exit_data(polycap_transmission_efficiencies *efficiencies, int64_t *n_exit,
+	polycap_vector3 **exit_coords, polycap_vector3 **exit_direction, polycap_vector3 **exit_elecv, int64_t **n_refl, double **d_travel,
+	size_t *n_energies, double ***exit_weights, polycap_error **error)
+{
+	if (efficiencies == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_exit_data: efficiencies cannot be NULL");
+		return false;
+	}
+	const struct _polycap_images *im = efficiencies->images;
+	if (im == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_exit_data: source->images cannot be NULL");
+		return false;
+	}
+	*n_exit = im->i_exit;
+	*n_energies = efficiencies->n_energies;
+	if (im->i_start == 0) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_exit_data: no photon start events in efficiencies");
+		return false;
+	}
+	const size_t n = (size_t)im->i_exit, ne = efficiencies->n_energies;
+	*exit_coords = malloc(sizeof(polycap_vector3) * n);
+	*exit_direction = malloc(sizeof(polycap_vector3) * n);
+	*exit_elecv = malloc(sizeof(polycap_vector3) * n);
+	*n_refl = malloc(sizeof(int64_t) * n);
+	*d_travel = malloc(sizeof(double) * n);
+	*exit_weights = calloc(n ? n : 1, sizeof(double *));
+	if (*exit_coords == NULL || *exit_direction == NULL || *exit_elecv == NULL || *n_refl == NULL || *d_travel == NULL || *exit_weights == NULL) {
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_source_get_exit_data: could not allocate memory for exit data -> %s", strerror(errno));
+		return false;
+	}
+	for (size_t i = 0; i < n; i++) {
+		(*n_refl)[i] = im->pc_exit_nrefl[i];
+		(*d_travel)[i] = im->pc_exit_dtravel[i];
+		(*exit_coords)[i].x = im->pc_exit_coords[0][i];
+		(*exit_coords)[i].y = im->pc_exit_coords[1][i];
+		(*exit_coords)[i].z = im->pc_exit_coords[2][i];
+		(*exit_direction)[i] = pc_unit_from_xy(im->pc_exit_dir[0][i], im->pc_exit_dir[1][i]);
+		(*exit_elecv)[i] = pc_unit_from_xy(im->pc_exit_elecv[0][i], im->pc_exit_elecv[1][i]);
+		(*exit_weights)[i] = malloc(sizeof(double) * ne);
+		if ((*exit_weights)[i] == NULL) {
+			polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_source_get_exit_data: could not allocate memory for (*exit_weights)[i] -> %s", strerror(errno));
+			return false;
+		}
+		memcpy((*exit_weights)[i], im->exit_coord_weights + i*ne, sizeof(double) * ne);
+	}
+	return true;
+}
+
+bool polycap_transmission_efficiencies_get_extleak_data(polycap_transmission_efficiencies *efficiencies, polycap_leak ***leaks, int64_t *n_leaks, polycap_error **error)
+{
+	if (efficiencies == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_extleak_data: efficiencies cannot be NULL");
+		return false;
+	}
+	if (efficiencies->images == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_extleak_data: source->images cannot be NULL");
+		return false;
+	}
+	if (n_leaks) *n_leaks = 0;
+	if (leaks) *leaks = NULL;
+	polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_extleak_data: no extleak events in efficiencies");
+	return false;
+}
+
+bool polycap_transmission_efficiencies_get_intleak_data(polycap_transmission_efficiencies *efficiencies, polycap_leak ***leaks, int64_t *n_leaks, polycap_error **error)
+{
+	if (efficiencies == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_intleak_data: efficiencies cannot be NULL");
+		return false;
+	}
+	if (efficiencies->images == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_intleak_data: source->images cannot be NULL");
+		return false;
+	}
+	if (n_leaks) *n_leaks = 0;
+	if (leaks) *leaks = NULL;
+	polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_getintleak_data: no intleak events in efficiencies");
+	return false;
+}
+
+bool polycap_transmission_efficiencies_write_hdf5(polycap_transmission_efficiencies *efficiencies, const char *filename, polycap_error **error)
+{
+	if (efficiencies == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_transmission_efficiencies_write_hdf5: efficiencies cannot be NULL");
+		return false;
+	}
+	if (filename == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_transmission_efficiencies_write_hdf5: filename cannot be NULL");
+		return false;
+	}
+	polycap_set_error_literal(error, POLYCAP_ERROR_UNSUPPORTED, "polycap_transmission_efficiencies_write_hdf5: the HDF5 writer is not part of the MI355X build yet; use the getters");
+	return false;
+}

@@ -1,0 +1,172 @@
+"""Python front-end of the thin HIP C-ABI (include/polycap-hip.h): numpy in, numpy out.
+
+TraceContext wraps one pc_hip_ctx (problem resident on one GPU).  Everything here calls into
+libpolycap.so; nothing is computed in Python and nothing falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _cabi
+from ._cabi import Problem, dptr, c_int64_p
+
+
+class HipError(RuntimeError):
+    def __init__(self, where, status):
+        msg = _cabi.lib().pc_hip_last_error()
+        super().__init__("%s failed (%d): %s" % (where, status, msg.decode() if msg else ""))
+        self.status = status
+
+
+def device_count():
+    return int(_cabi.lib().pc_hip_device_count())
+
+
+IMG_FIELDS = ("src_start_x", "src_start_y", "pc_start_x", "pc_start_y", "pc_start_dir_x", "pc_start_dir_y",
+              "pc_start_elecv_x", "pc_start_elecv_y", "pc_exit_x", "pc_exit_y", "pc_exit_z",
+              "pc_exit_dir_x", "pc_exit_dir_y", "pc_exit_elecv_x", "pc_exit_elecv_y", "nrefl", "dtravel")
+
+
+class TraceContext:
+    """One problem (optic + glass + energies + source) uploaded to one MI355X."""
+
+    def __init__(self, problem, device=0):
+        if not isinstance(problem, Problem):
+            raise TypeError("problem must be a polycap_amd.Problem")
+        self.problem = problem
+        self._L = _cabi.lib()
+        h = C.c_void_p()
+        st = self._L.pc_hip_ctx_create(C.byref(problem.s), int(device), C.byref(h))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_ctx_create", st)
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pc_hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_option(self, name, value):
+        st = self._L.pc_hip_set_option(self._h, name.encode(), int(value))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_set_option", st)
+
+    # -- polycap_photon_launch for a batch of explicit photons
+    def launch_photons(self, start, direction, elecv):
+        st_ = np.ascontiguousarray(start, dtype=np.float64).reshape(-1, 3)
+        di = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+        ev = np.ascontiguousarray(elecv, dtype=np.float64).reshape(-1, 3)
+        n = st_.shape[0]
+        ne = self.problem.n_energies
+        rc = np.zeros(n, dtype=np.int32)
+        w = np.zeros((n, ne))
+        ec, ed, ee = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 3))
+        ir = np.zeros(n, dtype=np.int64)
+        dt = np.zeros(n)
+        st = self._L.pc_hip_launch_photons(self._h, n, dptr(st_), dptr(di), dptr(ev),
+                                           rc.ctypes.data_as(C.POINTER(C.c_int32)), dptr(w), dptr(ec), dptr(ed), dptr(ee),
+                                           ir.ctypes.data_as(c_int64_p), dptr(dt))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_launch_photons", st)
+        return dict(rc=rc, weights=w, exit_coords=ec, exit_dir=ed, exit_elecv=ee, i_refl=ir, d_travel=dt)
+
+    # -- polycap_source_get_photon on the device
+    def sample_photons(self, seed, slots, attempts=None):
+        slots = np.ascontiguousarray(slots, dtype=np.int64)
+        n = slots.shape[0]
+        attempts = np.zeros(n, dtype=np.uint32) if attempts is None else np.ascontiguousarray(attempts, dtype=np.uint32)
+        out = np.zeros((n, 12))
+        st = self._L.pc_hip_sample_photons(self._h, int(seed), n, slots.ctypes.data_as(c_int64_p),
+                                           attempts.ctypes.data_as(C.POINTER(C.c_uint32)), dptr(out))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_sample_photons", st)
+        return out
+
+    # -- polycap_source_get_transmission_efficiencies for a slot range
+    def run(self, seed, slot0, n_slots, max_attempts=1 << 20, keep_images=False):
+        st = self._L.pc_hip_transmission_run(self._h, int(seed), int(slot0), int(n_slots), int(max_attempts), int(bool(keep_images)))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_transmission_run", st)
+        self._last_n = int(n_slots)
+
+    def wait(self):
+        ms = C.c_float(0)
+        st = self._L.pc_hip_transmission_wait(self._h, C.byref(ms))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_transmission_wait", st)
+        return float(ms.value)
+
+    def totals(self, check=True):
+        ne = self.problem.n_energies
+        sw = np.zeros(ne)
+        cnt = np.zeros(6, dtype=np.int64)
+        fx = np.zeros(2 * ne, dtype=np.uint64)
+        st = self._L.pc_hip_transmission_totals(self._h, dptr(sw), cnt.ctypes.data_as(c_int64_p),
+                                                fx.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if st != _cabi.PC_HIP_OK and (check or st != _cabi.PC_HIP_ERR_ATTEMPTS):
+            raise HipError("pc_hip_transmission_totals", st)
+        return dict(sum_weights=sw, counters=cnt, sumw_fixed=fx.reshape(ne, 2),
+                    i_exit=int(cnt[0]), not_entered=int(cnt[1]), not_transmitted=int(cnt[2]), sum_irefl=int(cnt[3]),
+                    failed_slots=int(cnt[4]), launches=int(cnt[5]), i_start=int(cnt[0] + cnt[1] + cnt[2]))
+
+    def images(self, first=0, count=None):
+        count = self._last_n - first if count is None else count
+        ne = self.problem.n_energies
+        planes = np.zeros((17, count))
+        nrefl = np.zeros(count, dtype=np.int64)
+        w = np.zeros((count, ne))
+        s = _cabi.ImagesS()
+        order = [("src_start_coords", 2), ("pc_start_coords", 2), ("pc_start_dir", 2), ("pc_start_elecv", 2),
+                 ("pc_exit_coords", 3), ("pc_exit_dir", 2), ("pc_exit_elecv", 2)]
+        k = 0
+        for name, m in order:
+            arr = getattr(s, name)
+            for j in range(m):
+                arr[j] = dptr(planes[k])
+                k += 1
+        s.pc_exit_nrefl = nrefl.ctypes.data_as(c_int64_p)
+        s.pc_exit_dtravel = dptr(planes[16])
+        s.exit_coord_weights = dptr(w)
+        st = self._L.pc_hip_transmission_images(self._h, int(first), int(count), C.byref(s))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_transmission_images", st)
+        planes[15] = nrefl
+        return dict(images=planes.T.copy(), exit_weights=w, nrefl=nrefl)
+
+    def transmission(self, seed, slot0, n_slots, max_attempts=1 << 20, keep_images=False):
+        """run + wait + totals (+ images) in one call."""
+        self.run(seed, slot0, n_slots, max_attempts, keep_images)
+        ms = self.wait()
+        r = self.totals()
+        r["kernel_ms"] = ms
+        r["efficiencies"] = efficiencies(r["sum_weights"], r["counters"])
+        if keep_images:
+            r.update(self.images(0, n_slots))
+        return r
+
+
+def efficiencies(sum_weights, counters):
+    sw = np.ascontiguousarray(sum_weights, dtype=np.float64)
+    cnt = np.ascontiguousarray(counters, dtype=np.int64)
+    if cnt.shape[0] < 6:
+        cnt = np.concatenate([cnt, np.zeros(6 - cnt.shape[0], dtype=np.int64)])
+    eff = np.zeros_like(sw)
+    _cabi.lib().pc_hip_efficiencies(sw.shape[0], dptr(sw), cnt.ctypes.data_as(c_int64_p), dptr(eff))
+    return eff
+
+
+def fixed_to_double(lo, hi):
+    return float(_cabi.lib().pc_hip_fixed_to_double(int(lo), int(hi)))

@@ -1,0 +1,106 @@
+/*
+ * pc_emul.cpp -- TEST-ONLY host compile of the device header (polycap_amd/csrc/hip/pc_device.h).
+ *
+ * Drives the per-photon state machine (NEW -> MARCH <-> EVENT -> DONE) one photon at a time on the CPU so
+ * that the `-m "not gpu"` suite can compare the device logic (certified skipping, hoisted Fresnel terms)
+ * with the oracle on identical photons.  It is built into tests/emul/libpc_emul.so by the tests and is
+ * never linked into, loaded by or shipped with libpolycap: the product has no CPU trace path.
+ */
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pc_problem.h"
+
+namespace {
+
+struct Emul {
+	pc_host_tables t;
+	pc_tables T;
+};
+
+int setup(const pc_hip_problem *p, int literal, Emul &E)
+{
+	std::string err;
+	int rc = pc_build_tables(p, E.t, err);
+	if (rc) return rc;
+	E.t.pm.literal = literal;
+	E.T.z = E.t.z.data(); E.T.cap = E.t.cap.data(); E.T.zh = E.t.zh.data();
+	E.T.cap2 = E.t.cap2.data(); E.T.hexd = E.t.hexd.data(); E.T.ext = E.t.ext.data();
+	return 0;
+}
+
+template <int NE>
+int run_photon(const Emul &E, pc_photon<NE> &ph, double x, double y, double z, double dx, double dy, double dz,
+               double ex, double ey, double ez, int64_t *stats)
+{
+	int st = pc_launch_init(E.T, E.t.pm, ph, x, y, z, dx, dy, dz, ex, ey, ez);
+	while (st != PC_ST_DONE) {
+		if (st == PC_ST_MARCH) {
+			st = pc_march_step(E.T, E.t.pm, ph);
+			if (stats && st == PC_ST_MARCH) stats[0]++;
+		} else {
+			st = pc_event(E.T, E.t.pm, E.t.ec.data(), ph);
+			if (stats) stats[1]++;
+		}
+	}
+	return ph.rc;
+}
+
+} // namespace
+
+extern "C" {
+
+int emul_launch_batch(const pc_hip_problem *p, int literal, int use_regs, int64_t n,
+                      const double *start, const double *dir, const double *elecv,
+                      int32_t *rc, double *weights, double *exit_coords, double *exit_dir, double *exit_elecv,
+                      int64_t *i_refl, double *d_travel, int64_t *stats)
+{
+	Emul E;
+	int r = setup(p, literal, E);
+	if (r) return r;
+	const size_t ne = p->n_energies;
+	if (stats) stats[0] = stats[1] = 0;
+	for (int64_t j = 0; j < n; j++) {
+		const double *s = start + 3*j, *d = dir + 3*j, *e = elecv + 3*j;
+		double P[3], D[3], Ev[3], dt; int ir, code;
+		if (use_regs && ne == 1) {
+			pc_photon<1> ph; ph.wmem = nullptr; ph.wstride = 0;
+			code = run_photon(E, ph, s[0], s[1], s[2], d[0], d[1], d[2], e[0], e[1], e[2], stats);
+			weights[j] = ph.w[0];
+			P[0]=ph.Px; P[1]=ph.Py; P[2]=ph.Pz; D[0]=ph.dx; D[1]=ph.dy; D[2]=ph.dz; Ev[0]=ph.ex; Ev[1]=ph.ey; Ev[2]=ph.ez;
+			ir = ph.irefl; dt = ph.dtravel;
+		} else {
+			pc_photon<0> ph; ph.wmem = weights + (size_t)j*ne; ph.wstride = 1;
+			code = run_photon(E, ph, s[0], s[1], s[2], d[0], d[1], d[2], e[0], e[1], e[2], stats);
+			P[0]=ph.Px; P[1]=ph.Py; P[2]=ph.Pz; D[0]=ph.dx; D[1]=ph.dy; D[2]=ph.dz; Ev[0]=ph.ex; Ev[1]=ph.ey; Ev[2]=ph.ez;
+			ir = ph.irefl; dt = ph.dtravel;
+		}
+		rc[j] = code;
+		memcpy(exit_coords + 3*j, P, sizeof P);
+		memcpy(exit_dir + 3*j, D, sizeof D);
+		memcpy(exit_elecv + 3*j, Ev, sizeof Ev);
+		i_refl[j] = ir;
+		d_travel[j] = dt;
+	}
+	return 0;
+}
+
+int emul_sample(const pc_hip_problem *p, uint64_t seed, int64_t n, const int64_t *slots, const uint32_t *attempts, double *out)
+{
+	Emul E;
+	int r = setup(p, 0, E);
+	if (r) return r;
+	for (int64_t j = 0; j < n; j++) {
+		pc_start s;
+		if (E.t.pm.generic_src) pc_sample_photon<true>(E.t.pm, seed, (uint64_t)slots[j], attempts[j], s);
+		else pc_sample_photon<false>(E.t.pm, seed, (uint64_t)slots[j], attempts[j], s);
+		double *o = out + 12*j;
+		o[0]=s.x; o[1]=s.y; o[2]=s.z; o[3]=s.dx; o[4]=s.dy; o[5]=s.dz; o[6]=s.ex; o[7]=s.ey; o[8]=s.ez;
+		o[9]=s.srcx; o[10]=s.srcy; o[11]=0.;
+	}
+	return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,67 @@
+"""TEST-ONLY: host compile of the device header (see pc_emul.cpp); never used by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from polycap_amd._cabi import ProblemS, c_double_p, c_int64_p, dptr
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libpc_emul.so")
+        srcs = [os.path.join(_HERE, "pc_emul.cpp"),
+                os.path.join(_ROOT, "polycap_amd", "csrc", "hip", "pc_device.h"),
+                os.path.join(_ROOT, "polycap_amd", "csrc", "hip", "pc_problem.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+                                   "-ffp-contract=off", "-mfma",   # same IEEE operation sequence as the gfx950 build (fma only where written)
+                                   "-I" + os.path.join(_ROOT, "include"),
+                                   "-I" + os.path.join(_ROOT, "polycap_amd", "csrc", "hip"),
+                                   "-o", so, srcs[0]])
+        L = C.CDLL(so)
+        L.emul_launch_batch.argtypes = [C.POINTER(ProblemS), C.c_int, C.c_int, C.c_int64, c_double_p, c_double_p, c_double_p,
+                                        C.POINTER(C.c_int32), c_double_p, c_double_p, c_double_p, c_double_p,
+                                        c_int64_p, c_double_p, c_int64_p]
+        L.emul_launch_batch.restype = C.c_int
+        L.emul_sample.argtypes = [C.POINTER(ProblemS), C.c_uint64, C.c_int64, c_int64_p, C.POINTER(C.c_uint32), c_double_p]
+        L.emul_sample.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def launch_batch(problem, start, direction, elecv, literal=False, use_regs=True):
+    st = np.ascontiguousarray(start, dtype=np.float64).reshape(-1, 3)
+    di = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+    ev = np.ascontiguousarray(elecv, dtype=np.float64).reshape(-1, 3)
+    n = st.shape[0]
+    rc = np.zeros(n, dtype=np.int32)
+    w = np.zeros((n, problem.n_energies))
+    ec, ed, ee = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 3))
+    ir = np.zeros(n, dtype=np.int64)
+    dt = np.zeros(n)
+    stats = np.zeros(2, dtype=np.int64)
+    r = lib().emul_launch_batch(C.byref(problem.s), int(literal), int(use_regs), n, dptr(st), dptr(di), dptr(ev),
+                                rc.ctypes.data_as(C.POINTER(C.c_int32)), dptr(w), dptr(ec), dptr(ed), dptr(ee),
+                                ir.ctypes.data_as(c_int64_p), dptr(dt), stats.ctypes.data_as(c_int64_p))
+    if r:
+        raise RuntimeError("emul_launch_batch failed: %d" % r)
+    return dict(rc=rc, weights=w, exit_coords=ec, exit_dir=ed, exit_elecv=ee, i_refl=ir, d_travel=dt,
+                fast_nodes=int(stats[0]), events=int(stats[1]))
+
+
+def sample(problem, seed, slots, attempts):
+    slots = np.ascontiguousarray(slots, dtype=np.int64)
+    attempts = np.ascontiguousarray(attempts, dtype=np.uint32)
+    out = np.zeros((slots.shape[0], 12))
+    r = lib().emul_sample(C.byref(problem.s), seed, slots.shape[0], slots.ctypes.data_as(c_int64_p),
+                          attempts.ctypes.data_as(C.POINTER(C.c_uint32)), dptr(out))
+    if r:
+        raise RuntimeError("emul_sample failed: %d" % r)
+    return out

@@ -1,0 +1,62 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol declared in include/*.h."""
+import ctypes
+import os
+import re
+
+from tests.conftest import ROOT
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith("#"))
+    names = re.findall(r"POLYCAP_EXTERN\s+[^;(]*?\b(\w+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_all_declared_symbols_are_exported():
+    import polycap_amd
+    L = polycap_amd.lib()
+    declared = _declared("polycap.h") + _declared("polycap-hip.h")
+    assert len(declared) >= 60
+    missing = [n for n in declared if not hasattr(L, n)]
+    assert not missing, missing
+    for must in ("polycap_source_get_transmission_efficiencies", "polycap_photon_launch", "polycap_source_get_photon",
+                 "pc_hip_launch_photons", "pc_hip_transmission_run", "pc_hip_sample_photons"):
+        assert must in declared
+
+
+def test_forwarding_headers_compile(tmp_path):
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include <polycap-photon.h>\n#include <polycap-source.h>\n#include <polycap.h>\n'
+                   'int main(void){ polycap_vector3 v = {0,0,1}; (void)v; return POLYCAP_VERSION_MAJOR == 1 ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                           "-o", str(tmp_path / "t.o")])
+
+
+def test_no_device_fails_loudly():
+    """Without a GPU the trace entry points must fail, never fall back to a CPU path."""
+    import numpy as np
+    import polycap_amd
+    if polycap_amd.device_count() > 0:
+        return
+    z = np.linspace(0, 1, 11)
+    prob = polycap_amd.Problem(z, np.full(11, 1e-3), np.full(11, 0.1), 0., 1000, 2.23, [10.], [42.5], [0.5])
+    try:
+        polycap_amd.TraceContext(prob)
+    except polycap_amd.HipError as e:
+        assert e.status == -1 and "no HIP device" in str(e)
+    else:
+        raise AssertionError("TraceContext must not work without a GPU")
+
+
+def test_product_never_references_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "polycap_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", ".cpp", ".pyx")):
+                t = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"\boracle\b|pyoracle|liboracle|tests\.emul|pc_emul", t):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad

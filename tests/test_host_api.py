@@ -1,0 +1,154 @@
+"""Host-side logic of libpolycap through the reference-shaped API (no GPU needed): profiles, descriptions,
+sources, the .inp parser, optical constants and the error convention.  Expected values are the reference's
+own test expectations (tests/profile.c, tests/description.c, tests/source.c, tests/python.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import EXAMPLE
+from tests.common import TEST_SHAPE
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from polycap_amd import capi
+    return capi
+
+
+def test_profile_shapes_match_oracle(capi, oracle):
+    # conical and ellipsoidal generators: same formulas as the oracle restatement, bit for bit
+    for ptype in (0, 2):
+        args = (9., 0.2065, 0.0585, 0.00035, 9.9153e-5, 1000., 0.5)
+        p = capi.Profile(ptype, *args)
+        o = oracle.Optic.from_shape(ptype, *args, 0., 200000, 2.23)
+        assert np.array_equal(p.get_z(), o.z) and np.array_equal(p.get_cap(), o.cap) and np.array_equal(p.get_ext(), o.ext)
+    # confocal (collimating) ellipsoid branch
+    p = capi.Profile(2, 6., 2e-5, 2e-4, 1e-5, 1e-4, 1.0, 1.0)
+    o = oracle.Optic.from_shape(2, 6., 2e-5, 2e-4, 1e-5, 1e-4, 1.0, 1.0, 0., 1000, 2.23)
+    assert np.array_equal(p.get_ext(), o.ext, equal_nan=True)
+
+
+def test_profile_paraboloidal_fit(capi):
+    # reference tests/profile.c:55-57: a paraboloidal profile can be built; the exterior is the least-squares parabola
+    # through the entrance, exit and the two focal-line points (src/polycap-profile.c:149-169)
+    L, ru, rd, fu, fd = 6., 2e-5, 2e-4, 1.0, 1.0
+    p = capi.Profile(capi.Profile.PARABOLOIDAL, L, ru, rd, 1e-5, 1e-4, fu, fd)
+    x = np.array([0., fu / 10., L - fd / 10., L])
+    y = np.array([ru, ru / fu * x[1] + ru, (rd / (L - (L + fd))) * (x[2] - L) + rd, rd])
+    coef = np.linalg.lstsq(np.vander(x, 3, increasing=True), y, rcond=None)[0]
+    z = p.get_z()
+    assert np.allclose(p.get_ext(), coef[0] + coef[1] * z + coef[2] * z * z, rtol=1e-9, atol=1e-15)
+    assert z[0] == 0 and z[-1] == L and len(z) == 1000
+
+
+def test_profile_errors_and_arrays(capi):
+    with pytest.raises(ValueError, match="polycap_profile_new: length must be greater than 0.0"):
+        capi.Profile(capi.Profile.CONICAL, -1, 2e-5, 2e-4, 1e-5, 1e-4, 1.0, 1.0)
+    with pytest.raises(IOError):
+        capi.Profile.new_from_file("this-file-does-not-exist", "this-file-also-does-not-exist", "neither-does-this-one")
+    assert (capi.Profile.CONICAL, capi.Profile.PARABOLOIDAL, capi.Profile.ELLIPSOIDAL) == (0, 1, 2)
+    ext, cap, z = np.linspace(2e-5, 2e-4, 1000), np.linspace(1e-5, 1e-4, 1000), np.linspace(0., 6., 1000)
+    p = capi.Profile.new_from_arrays(ext, cap, z)
+    assert np.array_equal(p.get_ext(), ext) and np.array_equal(p.get_cap(), cap) and np.array_equal(p.get_z(), z)
+    p = capi.Profile.new_from_file(*(os.path.join(EXAMPLE, "xos1." + e) for e in ("prf", "axs", "ext")))
+    assert len(p.get_z()) == 1000 and p.get_cap()[0] == 0.00035 and p.get_ext()[0] == 0.2065
+
+
+def test_description_errors(capi):
+    prof = capi.Profile(*TEST_SHAPE)
+    comp = {"O": 53.0, "Si": 47.0}
+    with pytest.raises(ValueError, match="Invalid chemical symbol"):
+        capi.Description(prof, 0.0, 1000, {"Bad": 53.0, "Ugly": 47.0}, 2.23)
+    with pytest.raises(ValueError, match="polycap_description_new: n_cap must be greater than 1"):
+        capi.Description(prof, 0.0, 0, comp, 2.23)
+    with pytest.raises(ValueError, match="polycap_description_new: density must be greater than 0.0"):
+        capi.Description(prof, 0.0, 1000, comp, 0.0)
+    with pytest.raises(ValueError, match="polycap_description_new: sig_rough must be greater than or equal to zero"):
+        capi.Description(prof, -1.0, 1000, comp, 2.23)
+    with pytest.raises(ValueError, match="composition cannot be empty"):
+        capi.Description(prof, 0.0, 1000, {}, 2.23)
+    with pytest.raises(ValueError, match="Invalid chemical formula"):
+        capi.Description(prof, 0.0, 1000, "sjalalala", 2.23)
+    with pytest.raises(TypeError, match="composition must be a dictionary or a string"):
+        capi.Description(prof, 0.0, 1000, 25, 2.23)
+    capi.Description(prof, 0.0, 200000, comp, 2.23)
+    capi.Description(prof, 0.0, 200000, "SiO2", 2.23)
+    # a profile whose capillaries poke out of the exterior is rejected (src/polycap-description.c:218-229)
+    bad = capi.Profile.new_from_arrays(np.full(200, 0.01), np.full(200, 0.009), np.linspace(0, 1, 200))
+    with pytest.raises(ValueError, match="description->profile is faulty"):
+        capi.Description(bad, 0.0, 200000, comp, 2.23)
+
+
+def test_rng_and_photon_argument_checks(capi):
+    assert isinstance(capi.Rng(), capi.Rng) and isinstance(capi.Rng(12345678), capi.Rng)
+    with pytest.raises(TypeError):
+        capi.Rng("this-is-not-a-seed")
+    with pytest.raises(OverflowError):
+        capi.Rng(-523)
+    prof = capi.Profile(*TEST_SHAPE)
+    desc = capi.Description(prof, 0.0, 200000, {"O": 53.0, "Si": 47.0}, 2.23)
+    with pytest.raises(ValueError):
+        capi.Photon(None, (0, 0, 0), (0.005, -0.005, 0.1), (0.5, 0.5, 0))
+    with pytest.raises(ValueError):
+        capi.Photon(desc, (0, 0, -1.), (0.005, -0.005, 0.1), (0.5, 0.5, 0))
+    ph = capi.Photon(desc, (0, 0, 0), (0.005, -0.005, 0.1), (0.5, 0.5, 0))
+    assert ph.start_coords == (0, 0, 0) and ph.d_travel == 0 and ph.i_refl == 0
+    with pytest.raises(ValueError, match="energies"):
+        ph.launch([0.5])              # energy below 1 keV is rejected before any device work
+    with pytest.raises(NotImplementedError):
+        ph.launch([10.0], leak_calc=True)
+
+
+def test_source_new_and_from_file(capi, known):
+    prof = capi.Profile(*TEST_SHAPE)
+    desc = capi.Description(prof, 0.0, 200000, {"O": 53.0, "Si": 47.0}, 2.23)
+    E = np.array([1, 5, 10, 15, 20, 25, 30.])
+    for bad in (dict(d_source=-1), dict(src_x=-1), dict(src_y=0), dict(hor_pol=1.5)):
+        kw = dict(d_source=2000., src_x=0.2065, src_y=0.2065, hor_pol=0.5)
+        kw.update(bad)
+        with pytest.raises(ValueError, match="polycap_source_new"):
+            capi.Source(desc, kw["d_source"], kw["src_x"], kw["src_y"], 0., 0., 0., 0., kw["hor_pol"], E)
+    with pytest.raises(ValueError, match="energies must be greater than 1 and smaller than 100"):
+        capi.Source(desc, 2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.5, np.array([0.5]))
+    capi.Source(desc, 2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.5, E)
+    with pytest.raises(ValueError):
+        capi.Source.new_from_file(None)
+    with pytest.raises(IOError):
+        capi.Source.new_from_file("this-file-does-not-exist")
+    src = capi.Source.new_from_file(os.path.join(EXAMPLE, "ellip_l9.inp"))
+    with pytest.raises(ValueError, match="n_photons must be greater than 1"):
+        src.get_transmission_efficiencies(-1, -1)
+    with pytest.raises(NotImplementedError):
+        src.get_transmission_efficiencies(1, 10, leak_calc=True)
+
+
+def test_inp_decks_and_open_area(known):
+    import polycap_amd
+    p = polycap_amd.problem_from_inp(os.path.join(EXAMPLE, "ellip_l9.inp"))
+    # reference tests/source.c:116: open area of ellip_l9.inp
+    n_shells = round(np.sqrt(12. * p.n_cap - 3.) / 6. - 0.5)
+    ncap = ((n_shells + 0.5) * 6.) ** 2
+    ncap = (ncap + 3) / 12
+    open_area = (p.cap[0] ** 2 * np.pi) * ncap / (3. * np.sin(np.pi / 3) * p.ext[0] ** 2)
+    assert abs(open_area - known["test_optic"]["open_area"]) < 1e-5
+    assert p.n_energies == 291 and p.energies[0] == 1.0 and abs(p.energies[-1] - 30.0) < 1e-9   # (30-1)/0.1+1 truncated
+    assert p.n_cap == 200000 and p.nmax == 999 and p.source == (2000.0, 0.2065, 0.2065, 0.0, 0.0, 0.0, 0.0, 0.0)
+    x = polycap_amd.problem_from_inp(os.path.join(EXAMPLE, "xos1.inp"), energies=[10.0])
+    assert x.nmax == 999 and x.cap[0] == 0.00035 and x.ext[-1] == 0.0585 and x.sig_rough == 0.0
+    c = polycap_amd.problem_from_inp(os.path.join(EXAMPLE, "cone.inp"), energies=[10.0])
+    assert c.source[2] == 0.0   # the degenerate src_y = 0 deck
+
+
+def test_optical_constants_pin(known):
+    import polycap_amd
+    g = known["glass"]
+    amu, scatf, synthetic = polycap_amd.optical_constants(g["iz"], g["wi_percent"], g["density"], [g["energy_keV"]])
+    assert abs(scatf[0] - g["scatf"]) < g["scatf_tol"] and abs(amu[0] - g["amu"]) < g["amu_tol"]
+    assert not synthetic
+    amu, scatf, synthetic = polycap_amd.optical_constants(g["iz"], g["wi_percent"], g["density"], [1., 1.8, 1.9, 5., 30., 100.])
+    assert synthetic and np.all(amu > 0) and np.all(scatf > 0.3) and amu[2] > amu[1]    # Si K edge between 1.8 and 1.9 keV
+    with pytest.raises(ValueError, match="no optical constants for Z=82"):
+        polycap_amd.optical_constants([82], [1.0], 11.3, [10.0])
+    with pytest.raises(ValueError, match="energies"):
+        polycap_amd.optical_constants(g["iz"], g["wi_percent"], g["density"], [0.5])
