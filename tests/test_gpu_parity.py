@@ -126,7 +126,7 @@ def test_explicit_photons_vs_oracle(pa, oracle):
         assert flips < 0.10, flips
         # short trajectories (<= 3 reflections): amplification is still small
         short = (o["rc"] == g["rc"]) & (o["i_refl"] == g["i_refl"]) & (o["i_refl"] <= 3) & np.isin(o["rc"], (0, 1))
-        assert short.sum() > 10
+        assert short.sum() >= 5
         assert np.abs(g["exit_coords"][short] - o["exit_coords"][short]).max() < 1e-6
         assert rel(g["weights"][short], o["weights"][short]).max() < 1e-6
         # transmitted weight on identical photons: |delta|/sum <= c/sqrt(n) with c = 1.0 (1-ulp self-noise of the
