@@ -136,6 +136,7 @@ def main():
             "efficiency_10keV": float(eff[0]),
             "avg_reflections": float(counters[3]) / max(1, int(counters[0])),
             "started_per_exit": started / max(1, exited),
+            "scheduler": ctx.phase_stats(),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "pc_trace_kernel<1,0>", "kernel_ms": avg_ms,

@@ -104,6 +104,10 @@ POLYCAP_EXTERN int pc_hip_transmission_totals(pc_hip_ctx *ctx, double *sum_weigh
 /* Copies image planes of slots [first, first+count) (relative to slot0 of the last run) to the host. */
 POLYCAP_EXTERN int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const pc_hip_images *dst);
 
+/* Scheduler statistics of the last transmission run (diagnostics): {march steps, march lane-steps, event phases,
+ * event lanes, new phases, new lanes}, summed over all waves; lanes/phases = average active lanes per phase. */
+POLYCAP_EXTERN int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6]);
+
 /* efficiency formula of src/polycap-source.c:1066-1076 from (summed) totals */
 POLYCAP_EXTERN void pc_hip_efficiencies(size_t n_energies, const double *sum_weights, const int64_t counters[6], double *efficiencies);
 /* exact fixed-point (lo,hi) pair -> double */

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpolycap.so")
+LIB_PATH = os.environ.get("POLYCAP_AMD_LIB") or os.path.join(_HERE, "lib", "libpolycap.so")   # override: A/B builds only
 
 c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
@@ -104,6 +104,8 @@ def lib():
     L.pc_hip_transmission_totals.restype = C.c_int
     L.pc_hip_transmission_images.argtypes = [C.c_void_p, C.c_int64, C.c_int64, P(ImagesS)]
     L.pc_hip_transmission_images.restype = C.c_int
+    L.pc_hip_phase_stats.argtypes = [C.c_void_p, c_int64_p]
+    L.pc_hip_phase_stats.restype = C.c_int
     L.pc_hip_efficiencies.argtypes = [C.c_size_t, c_double_p, c_int64_p, c_double_p]
     L.pc_hip_efficiencies.restype = None
     L.pc_hip_fixed_to_double.argtypes = [C.c_uint64, C.c_uint64]

@@ -69,6 +69,7 @@ struct pc_tables {
 	const double *zh;    /* ext[i] / hexscale: capillary axis = (kx, ky) * zh[i]  (src/polycap-photon.c:624-627) */
 	const double *cap2;  /* cap[i]^2 */
 	const double *hexd;  /* sqrt(ext^2 - (ext/2)^2): centre-to-edge distance of the outer hexagon at node i */
+	const double *idz;   /* 1 / (z[i+1] - z[i]) */
 	const double *ext;
 };
 
@@ -79,6 +80,7 @@ struct pc_photon {
 	double ex, ey, ez;      /* exit_electric_vector */
 	double kx, ky;          /* capillary axis scale factors */
 	double sx, sy, ox, oy;  /* ray of the current trace call: p(z) = o + s*z */
+	double idzd;            /* 1 / dz of the current direction */
 	double C0;              /* |p - axis|^2 - cap^2 at node i (certificate chain) */
 	double dtravel;
 	double w[NE > 0 ? NE : 1]; /* NE > 0: one weight per energy in registers */
@@ -279,6 +281,7 @@ template <int NE>
 PC_HD void pc_trace_begin(pc_photon<NE> &ph)
 {
 	double idz = 1.0 / ph.dz;
+	ph.idzd = idz;
 	ph.sx = ph.dx * idz;
 	ph.sy = ph.dy * idz;
 	ph.ox = ph.Px - ph.sx * ph.Pz;
@@ -372,12 +375,12 @@ PC_HD int pc_launch_init(const pc_tables &T, const pc_params &Pm, pc_photon<NE> 
  *
  * Within segment i both the ray-to-axis offset q(u) and the capillary radius R(u) are linear in
  * u=(z-z_i)/(z_i+1-z_i), so g(u) = |q(u)|^2 - R(u)^2 = A u^2 + B u + C with A = |dq|^2 - dR^2 >= -dR^2.
- * A quadratic deviates from its chord by at most |A|/4 on [0,1], hence
- *     g(u) <= max(g(0), g(1)) + dR^2/4   for all u in [0,1].
- * If g(0) and g(1) are both below -(dRmax^2/4 + m) the photon is strictly inside the capillary over the
- * whole segment: the reference's quadratic (src/polycap-capil.c:119-157) has no root in the segment
- * (it returns -2/-3/-4/-5), the capillary lies inside the outer hexagon (non-boundary capillaries), so its
- * hexagon tests (src/polycap-capil.c:1263,1301) pass as well: the visit is a certain "miss" and is skipped.
+ * A quadratic deviates from its chord by at most |A|/4 on an interval of length <= 1, hence
+ *     g(u) <= max(g(u0), g(1)) + dR^2/4   for all u in [u0, 1].
+ * If g at both ends is below -(dRmax^2/4 + m) the photon is strictly inside the capillary over that whole
+ * stretch: the reference's quadratic (src/polycap-capil.c:119-157) has no admissible root there (it returns
+ * -2/-3/-4/-5), the capillary lies inside the outer hexagon (non-boundary capillaries), so its hexagon tests
+ * (src/polycap-capil.c:1263,1301) pass as well: the visit is a certain "miss" and is skipped.
  * adj = dRmax^2/4 + m with m ~ 1e6 x the rounding error of g.  Anything else goes to pc_event().
  * Cost: 6 FMA + 3 LDS reads per node.
  */
@@ -404,6 +407,46 @@ PC_HD int pc_march_ok(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph
 	return ok;
 }
 
+/* First segment of a trace call: the last interaction point P lies inside [z_i, z_i+1] and the reference only
+ * admits roots beyond P.z + 1e-5 (src/polycap-capil.c:134-171).  The certificate is evaluated on
+ * [z_lo, z_i+1], z_lo = max(z_i, P.z + 1e-5), with zh and cap interpolated linearly to z_lo.  The reference
+ * also tests the ray at z_i -- behind the photon -- against the outer hexagon (:1296-1308); that point can lie
+ * just outside the capillary, so the test is done explicitly here. */
+template <int NE>
+PC_HD int pc_march_first_ok(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph)
+{
+	const int i0 = ph.i, i1 = ph.i + 1;
+	double z0 = T.z[i0], z1 = T.z[i1], zh0 = T.zh[i0], zh1 = T.zh[i1];
+	double R0 = T.cap[i0], R1 = T.cap[i1], h0 = T.hexd[i0];
+	double qx1 = fma(-ph.kx, zh1, fma(ph.sx, z1, ph.ox));
+	double qy1 = fma(-ph.ky, zh1, fma(ph.sy, z1, ph.oy));
+	double C1 = fma(qx1, qx1, fma(qy1, qy1, -R1*R1));
+	double zlo = fmax(z0, ph.Pz + 1.e-5);
+	int ok;
+	if (zlo >= z1) {
+		ok = 1;                     /* no admissible root can lie in this segment */
+	} else {
+		double t = (zlo - z0) * T.idz[i0];
+		double zhl = fma(t, zh1 - zh0, zh0);
+		double Rl = fma(t, R1 - R0, R0);
+		double qx = fma(-ph.kx, zhl, fma(ph.sx, zlo, ph.ox));
+		double qy = fma(-ph.ky, zhl, fma(ph.sy, zlo, ph.oy));
+		double Cl = fma(qx, qx, fma(qy, qy, -Rl*Rl));
+		ok = (Cl < -Pm.adj) & (C1 < -Pm.adj);
+	}
+	/* ray at z_i inside the optic; boundary capillaries also test the axis at both nodes */
+	double px = fma(ph.sx, z0, ph.ox), py = fma(ph.sy, z0, ph.oy);
+	ok &= !(h0 > 0. && pc_outside_hexd(h0, px, py));
+	if (ph.bnd) {
+		double h1 = T.hexd[i1];
+		ok &= !pc_outside_hexd(h0, ph.kx*zh0, ph.ky*zh0);
+		ok &= !pc_outside_hexd(h1, ph.kx*zh1, ph.ky*zh1);
+	}
+	ok &= (ph.dz >= 0.);            /* backwards-flying photons keep the reference's literal path */
+	if (ok) { ph.C0 = C1; ph.i = i1; ph.first = 0; }
+	return ok;
+}
+
 /* certificate value at node idx for the current ray */
 template <int NE>
 PC_HD double pc_node_C(const pc_tables &T, const pc_photon<NE> &ph, int idx)
@@ -416,7 +459,10 @@ PC_HD double pc_node_C(const pc_tables &T, const pc_photon<NE> &ph, int idx)
 
 /* ------------------------------------------------------------------ full segment (reference quadratic)
  * src/polycap-capil.c:52-255.  Returns the reference's status; on 1, (hx,hy,hz) is the hit and (nx,ny,nz)
- * the unit surface normal.  (p0x,p0y) = ray at z_i (phot_coord0 of src/polycap-capil.c:1256-1258). */
+ * the unit surface normal.  (p0x,p0y) = ray at z_i (phot_coord0 of src/polycap-capil.c:1256-1258).
+ * Same quadratic, same root selection and guards as the reference; divisions by per-trace / per-segment
+ * constants are hoisted (1/dz of the direction, 1/(z_i+1 - z_i) from the table) and the normal is normalised
+ * once instead of four times. */
 template <int NE>
 PC_HD int pc_segment(const pc_tables &T, const pc_photon<NE> &ph, int i,
                      double &p0x, double &p0y, double &hx, double &hy, double &hz,
@@ -427,22 +473,22 @@ PC_HD int pc_segment(const pc_tables &T, const pc_photon<NE> &ph, int i,
 	double c0x = ph.kx*T.zh[i], c0y = ph.ky*T.zh[i];
 	double c1x = ph.kx*T.zh[i+1], c1y = ph.ky*T.zh[i+1];
 	double t0 = z0 - ph.Pz;
-	p0x = ph.Px + ph.dx * t0 / ph.dz;
-	p0y = ph.Py + ph.dy * t0 / ph.dz;
+	p0x = fma(ph.sx, t0, ph.Px);
+	p0y = fma(ph.sy, t0, ph.Py);
 	nx = 0.; ny = 0.; nz = 0.;
 	hx = hy = hz = 0.;
 	if (ph.dz < 0) return -1;          /* :85-88 */
-	if (z1 <= z0) return -1;           /* :97-100 */
 	double cdx = c1x - c0x, cdy = c1y - c0y, cdz = z1 - z0;
-	double icdz = 1.0 / cdz;
-	double ddx = ph.sx - cdx*icdz;
-	double ddy = ph.sy - cdy*icdz;
-	double rr = (R1 - R0)*icdz;
+	double icdz = T.idz[i];
+	double ddx = fma(-cdx, icdz, ph.sx);
+	double ddy = fma(-cdy, icdz, ph.sy);
+	double dR = R1 - R0;
+	double rr = dR*icdz;
 	double qx = p0x - c0x, qy = p0y - c0y;
-	double a = ddx*ddx + ddy*ddy - rr*rr;
-	double b = 2.*qx*ddx + 2.*qy*ddy - 2.*R0*rr;
-	double c = qx*qx + qy*qy - R0*R0;
-	double discr = b*b - 4.*a*c;
+	double a = fma(ddx, ddx, fma(ddy, ddy, -rr*rr));
+	double b = 2.*fma(qx, ddx, fma(qy, ddy, -R0*rr));
+	double c = fma(qx, qx, fma(qy, qy, -R0*R0));
+	double discr = fma(b, b, -4.*a*c);
 	if (discr < 0) return -2;
 	double last = ph.Pz;
 	if (discr == 0) {
@@ -466,26 +512,25 @@ PC_HD int pc_segment(const pc_tables &T, const pc_photon<NE> &ph, int i,
 	}
 	if (hz > z1) return -4;
 	if (hz < z0 || hz - last < 1.e-5) return -5;
-	double d_proj = (hz - z0) / ph.dz;
+	double d_proj = (hz - z0) * ph.idzd;
 	if (d_proj < 1.e-10) return -6;
-	hx = p0x + d_proj * ph.dx;
-	hy = p0y + d_proj * ph.dy;
-	/* :225-246 surface normal */
-	double s1 = qx*cdx + qy*cdy;                           /* (phot0-cap0).cap_dir, z component is 0 */
-	double s2 = ph.dx*cdx + ph.dy*cdy + ph.dz*cdz;         /* photon_dir.cap_dir */
-	double s3 = cdx*cdx + cdy*cdy + cdz*cdz;               /* |cap_dir|^2 */
-	double tpar = (d_proj + s1/s2) / (s3/s2);
-	double inx = hx - (c0x + tpar*cdx);
-	double iny = hy - (c0y + tpar*cdy);
-	double inz = hz - (z0 + tpar*cdz);
-	double idci = 1.0 / sqrt(inx*inx + iny*iny + inz*inz);
-	double idcc = 1.0 / sqrt(s3);
-	double tga = (R0 - R1) * idcc;
-	double cga = 1.0 / sqrt(1.0 + tga*tga);                /* cos(atan(t)) */
-	double sga = tga * cga;                                /* sin(atan(t)) */
-	nx = cga*inx*idci + sga*cdx*idcc;
-	ny = cga*iny*idci + sga*cdy*idcc;
-	nz = cga*inz*idci + sga*cdz*idcc;
+	hx = fma(d_proj, ph.dx, p0x);
+	hy = fma(d_proj, ph.dy, p0y);
+	/* :225-246 surface normal: radial unit vector tilted by the wall angle gamma, tan(gamma) = (R0-R1)/|cap_dir| */
+	double s1 = fma(qx, cdx, qy*cdy);                              /* (phot0-cap0).cap_dir, z component is 0 */
+	double s2 = fma(ph.dx, cdx, fma(ph.dy, cdy, ph.dz*cdz));       /* photon_dir.cap_dir */
+	double s3 = fma(cdx, cdx, fma(cdy, cdy, cdz*cdz));             /* |cap_dir|^2 */
+	double tpar = fma(d_proj, s2, s1) / s3;
+	double inx = hx - fma(tpar, cdx, c0x);
+	double iny = hy - fma(tpar, cdy, c0y);
+	double inz = hz - fma(tpar, cdz, z0);
+	double idci = 1.0 / sqrt(fma(inx, inx, fma(iny, iny, inz*inz)));
+	double tg = -dR / s3;                                           /* tan(gamma)/|cap_dir| */
+	/* n ~ in/|in| + tan(gamma) * cap_dir/|cap_dir|, normalised once (= cos(gamma) in/|in| + sin(gamma) cap_dir/|cap_dir|
+	 * of the reference up to its own final normalisation) */
+	nx = fma(inx, idci, tg*cdx);
+	ny = fma(iny, idci, tg*cdy);
+	nz = fma(inz, idci, tg*cdz);
 	pc_norm3(nx, ny, nz);
 	return 1;
 }
@@ -494,34 +539,24 @@ PC_HD int pc_segment(const pc_tables &T, const pc_photon<NE> &ph, int i,
  * src/polycap-capil.c:565-655 with polycap_refl_polar (:444-563) inlined: the geometry of the s/p split is
  * energy independent and hoisted; per energy only the complex Fresnel amplitudes remain.
  * cos(theta)=n.d and sin^2(theta)=1-cos^2 replace cos/sin(acos(.)); |r|^2 = |num|^2/|den|^2 replaces the
- * complex reciprocal + cabs.  Returns 1 keep, 0 absorbed, -1 error. */
+ * complex reciprocal + cabs; |n x d| = sin(theta) normalises the s direction.  The reference's new electric
+ * vector is |E_k| * f / |(|E| f)| for a common factor f (:546-559), i.e. the component-wise absolute value of
+ * the (unit) vector.  Returns 1 keep, 0 absorbed, -1 error. */
 template <int NE>
 PC_HD int pc_reflect(const pc_params &Pm, const pc_energy_const *EC, pc_photon<NE> &ph,
                      double nx, double ny, double nz)
 {
-	double alfa = ph.dx*nx + ph.dy*ny + ph.dz*nz;
+	double alfa = fma(ph.dx, nx, fma(ph.dy, ny, ph.dz*nz));
 	if (alfa < 0.) return -1;                                   /* :599-602 */
 	double ct = alfa;
 	double st2 = fma(-ct, ct, 1.0);
-	/* :520-529 */
-	double sdx = ny*ph.dz - ph.dy*nz;
-	double sdy = nz*ph.dx - ph.dz*nx;
-	double sdz = nx*ph.dy - ph.dx*ny;
-	pc_norm3(sdx, sdy, sdz);
-	double pdx = ph.dy*sdz - sdy*ph.dz;
-	double pdy = ph.dz*sdx - sdz*ph.dx;
-	double pdz = ph.dx*sdy - sdx*ph.dy;
-	pc_norm3(pdx, pdy, pdz);
-	/* :537-558 */
-	double angle_a = ph.ex*sdx + ph.ey*sdy + ph.ez*sdz;
-	double frac_s = angle_a*angle_a;
+	/* :520-537: s = (n x d)/|n x d|, |n x d|^2 = sin^2(theta); frac_s = (E.s)^2 */
+	double sdx = fma(ny, ph.dz, -ph.dy*nz);
+	double sdy = fma(nz, ph.dx, -ph.dz*nx);
+	double sdz = fma(nx, ph.dy, -ph.dx*ny);
+	double es = fma(ph.ex, sdx, fma(ph.ey, sdy, ph.ez*sdz));
+	double frac_s = (es*es) / fma(sdx, sdx, fma(sdy, sdy, sdz*sdz));
 	double frac_p = 1. - frac_s;
-	double angle_b = ph.ex*nx + ph.ey*ny + ph.ez*nz;
-	double angle_c = ph.ex*pdx + ph.ey*pdy + ph.ez*pdz;
-	double fa = angle_a*frac_s, fb = angle_b*frac_p, fc = angle_c*frac_p;
-	double f = sqrt(fa*fa + fb*fb + fc*fc);
-	double nex = fabs(ph.ex)*f, ney = fabs(ph.ey)*f, nez = fabs(ph.ez)*f;
-	pc_norm3(nex, ney, nez);
 
 	int keep = 0;
 	const int ne = (NE > 0) ? NE : Pm.n_energies;
@@ -529,9 +564,9 @@ PC_HD int pc_reflect(const pc_params &Pm, const pc_energy_const *EC, pc_photon<N
 		const pc_energy_const ec = EC[e];
 		if (ec.valid == 0.) return -1;
 		/* tmp = n_inv^2 * sin^2 ; csq = csqrt(1 - tmp)   (:503-505) */
-		double wr = 1.0 - ec.ninv2_re*st2;
+		double wr = fma(-ec.ninv2_re, st2, 1.0);
 		double wi = -ec.ninv2_im*st2;
-		double mag = sqrt(wr*wr + wi*wi);
+		double mag = sqrt(fma(wr, wr, wi*wi));
 		double csr, csi;
 		if (wr >= 0.) {
 			csr = sqrt(0.5*(mag + wr));
@@ -542,24 +577,25 @@ PC_HD int pc_reflect(const pc_params &Pm, const pc_energy_const *EC, pc_photon<N
 			csi = copysign(sa, wi);
 		}
 		/* r_s = (cos - n*csq)/(cos + n*csq)   (:507-510) */
-		double tr = ec.n_re*csr - ec.n_im*csi;
-		double ti = ec.n_re*csi + ec.n_im*csr;
-		double nr = ct - tr, ni = -ti, dr = ct + tr, di = ti;
-		double r_s = (nr*nr + ni*ni) / (dr*dr + di*di);
+		double tr = fma(ec.n_re, csr, -ec.n_im*csi);
+		double ti = fma(ec.n_re, csi, ec.n_im*csr);
+		double nr = ct - tr, dr = ct + tr;
+		double Ns = fma(nr, nr, ti*ti), Ds = fma(dr, dr, ti*ti);
 		/* r_p = (csq - n*cos)/(csq + n*cos)   (:512-515) */
 		double ur = ec.n_re*ct, ui = ec.n_im*ct;
-		nr = csr - ur; ni = csi - ui; dr = csr + ur; di = csi + ui;
-		double r_p = (nr*nr + ni*ni) / (dr*dr + di*di);
-		double rtot = r_s*frac_s + r_p*frac_p;
+		double pr = csr - ur, pi_ = csi - ui, er = csr + ur, ei = csi + ui;
+		double Np = fma(pr, pr, pi_*pi_), Dp = fma(er, er, ei*ei);
+		/* rtot = R_s frac_s + R_p frac_p with one division */
+		double rtot = fma(frac_s*Ns, Dp, frac_p*Np*Ds) / (Ds*Dp);
 		if (rtot < 0. || rtot > 1.) return -1;                  /* :633-637 */
 		double cons1 = ec.rough_c*alfa;                         /* (1.01358*E)*alfa*sig_rough, :626 */
 		double r_rough = (ec.rough_c == 0.) ? 1.0 : exp(-1.*cons1*cons1);
-		double we = (NE > 0) ? ph.w[e] : ph.wmem[e*ph.wstride];
+		double we = (NE > 0) ? ph.w[NE > 0 ? e : 0] : ph.wmem[e*ph.wstride];
 		we = we * rtot * r_rough;
-		if (NE > 0) ph.w[e] = we; else ph.wmem[e*ph.wstride] = we;
+		if (NE > 0) ph.w[NE > 0 ? e : 0] = we; else ph.wmem[e*ph.wstride] = we;
 		if (we >= 1.e-4) keep = 1;
 	}
-	ph.ex = nex; ph.ey = ney; ph.ez = nez;
+	ph.ex = fabs(ph.ex); ph.ey = fabs(ph.ey); ph.ez = fabs(ph.ez);
 	return keep;
 }
 
@@ -581,7 +617,7 @@ PC_HD int pc_event(const pc_tables &T, const pc_params &Pm, const pc_energy_cons
 	}
 	double p0x, p0y, hx, hy, hz, nx, ny, nz;
 	int iesc = pc_segment(T, ph, i, p0x, p0y, hx, hy, hz, nx, ny, nz);
-	double cosalfa = nx*ph.dx + ny*ph.dy + nz*ph.dz;
+	double cosalfa = fma(nx, ph.dx, fma(ny, ph.dy, nz*ph.dz));
 	if (cosalfa < 0.) iesc = -5;                                /* acos(cosalfa) > pi/2, :1270-1273 */
 
 	if (iesc != 1) {
@@ -593,35 +629,39 @@ PC_HD int pc_event(const pc_tables &T, const pc_params &Pm, const pc_energy_cons
 		return PC_ST_MARCH;
 	}
 
-	/* :1277-1294 hit: still inside the optic? */
-	double cur_ext = ((T.ext[i] - T.ext[i+1])/(T.z[i] - T.z[i+1])) * (hz - T.z[i+1]) + T.ext[i+1];
-	if (Pm.mono) {
-		if (sqrt(hx*hx + hy*hy) >= cur_ext) { ph.rc = -1; return PC_ST_DONE; }
-	} else if (ph.bnd) {
-		if (pc_outside_hex(cur_ext, hx, hy)) { ph.rc = -1; return PC_ST_DONE; }
+	/* :1277-1294 hit: still inside the optic?  (implied for non-boundary capillaries: the wall lies inside the hexagon) */
+	if (ph.bnd) {
+		double cur_ext = ((T.ext[i] - T.ext[i+1])/(T.z[i] - T.z[i+1])) * (hz - T.z[i+1]) + T.ext[i+1];
+		if (Pm.mono) {
+			if (sqrt(hx*hx + hy*hy) >= cur_ext) { ph.rc = -1; return PC_ST_DONE; }
+		} else {
+			if (pc_outside_hex(cur_ext, hx, hy)) { ph.rc = -1; return PC_ST_DONE; }
+		}
 	}
 	/* :1315-1324 */
 	double rx = hx - ph.Px, ry = hy - ph.Py, rz = hz - ph.Pz;
-	ph.dtravel += sqrt(rx*rx + ry*ry + rz*rz);
+	ph.dtravel += sqrt(fma(rx, rx, fma(ry, ry, rz*rz)));
 	ph.Px = hx; ph.Py = hy; ph.Pz = hz;
 	if (fabs(cosalfa) > 1.0) { ph.rc = -1; return PC_ST_DONE; } /* :1325-1327 */
 	/* :1330-1333 rescan: last node index < nmax with z <= hit z (z strictly increasing, z_i <= hz <= z_i+1) */
 	int ix = (hz >= T.z[i+1] && i + 1 < nmax) ? i + 1 : i;
 	/* :1334-1343 */
-	cur_ext = ((T.ext[ix+1] - T.ext[ix])/(T.z[ix+1] - T.z[ix])) * (hz - T.z[ix]) + T.ext[ix];
-	if (Pm.mono) {
-		if (hx*hx + hy*hy >= cur_ext) { ph.rc = -1; return PC_ST_DONE; }
-	} else if (ph.bnd) {
-		if (pc_outside_hex(cur_ext, hx, hy)) { ph.rc = -1; return PC_ST_DONE; }
+	if (ph.bnd) {
+		double cur_ext = ((T.ext[ix+1] - T.ext[ix])/(T.z[ix+1] - T.z[ix])) * (hz - T.z[ix]) + T.ext[ix];
+		if (Pm.mono) {
+			if (hx*hx + hy*hy >= cur_ext) { ph.rc = -1; return PC_ST_DONE; }
+		} else {
+			if (pc_outside_hex(cur_ext, hx, hy)) { ph.rc = -1; return PC_ST_DONE; }
+		}
 	}
 	/* :1345-1355 */
 	int r = pc_reflect(Pm, EC, ph, nx, ny, nz);
 	if (r == 0) { ph.rc = 0; return PC_ST_DONE; }
 	if (r != 1) { ph.rc = -1; return PC_ST_DONE; }
-	ph.dx = ph.dx - 2.0*cosalfa*nx;
-	ph.dy = ph.dy - 2.0*cosalfa*ny;
-	ph.dz = ph.dz - 2.0*cosalfa*nz;
-	pc_norm3(ph.dx, ph.dy, ph.dz);
+	/* mirror reflection of a unit vector about a unit normal stays unit: the reference's re-normalisation is a no-op up to rounding */
+	ph.dx = fma(-2.0*cosalfa, nx, ph.dx);
+	ph.dy = fma(-2.0*cosalfa, ny, ph.dy);
+	ph.dz = fma(-2.0*cosalfa, nz, ph.dz);
 	ph.irefl++;
 	ph.ntrace++;
 	if (ph.ntrace > nmax) { ph.rc = 1; return PC_ST_DONE; }     /* src/polycap-photon.c:912-919: at most nmax+1 calls */
@@ -635,7 +675,8 @@ template <int NE>
 PC_HD int pc_march_step(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph)
 {
 	if (ph.i >= Pm.nmax) { ph.rc = 1; return PC_ST_DONE; }
-	if (ph.first || Pm.literal) return PC_ST_EVENT;
+	if (Pm.literal) return PC_ST_EVENT;
+	if (ph.first) return pc_march_first_ok(T, Pm, ph) ? PC_ST_MARCH : PC_ST_EVENT;
 	return pc_march_ok(T, Pm, ph) ? PC_ST_MARCH : PC_ST_EVENT;
 }
 

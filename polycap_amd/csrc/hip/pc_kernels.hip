@@ -25,30 +25,34 @@
 #include "pc_device.h"
 #include "pc_problem.h"
 
-#define PC_BLOCK 256
+#define PC_BLOCK 512            /* maximum workgroup size the trace kernel is compiled for */
 #define PC_WAVE 64
 #define PC_CHUNK 128           /* slots a wave takes from the global counter at a time */
 #define PC_FIX_SCALE 4611686018427387904.0 /* 2^62 */
+#ifndef PC_MIN_WAVES
+#define PC_MIN_WAVES 4         /* __launch_bounds__ waves per SIMD the register allocator must leave room for */
+#endif
 
 /* --------------------------------------------------------------------------- kernel arguments */
 
-struct pc_img_planes {
-	double *src_start[2], *pc_start[2], *pc_start_dir[2], *pc_start_elecv[2];
-	double *pc_exit[3], *pc_exit_dir[2], *pc_exit_elecv[2];
-	long long *nrefl;
-	double *dtravel;
-	double *weights;           /* [n_slots * n_energies] */
-};
+/* Per-exit-photon image record in HBM: one contiguous record per slot (17 + n_energies doubles) so that a lane
+ * writes whole 64/128-byte segments instead of 18 scattered 8-byte words; pc_images_transpose_kernel turns a
+ * range of records into the reference's SoA planes (struct _polycap_images) when the host asks for them.
+ * Field order = pc_hip_images / the reference's plane order. */
+enum { PC_F_SRCX = 0, PC_F_SRCY, PC_F_STARTX, PC_F_STARTY, PC_F_SDIRX, PC_F_SDIRY, PC_F_SEVX, PC_F_SEVY,
+       PC_F_EXITX, PC_F_EXITY, PC_F_EXITZ, PC_F_EDIRX, PC_F_EDIRY, PC_F_EEVX, PC_F_EEVY, PC_F_NREFL, PC_F_DTRAVEL,
+       PC_F_WEIGHTS, PC_N_FIELDS = 17 };
 
 struct pc_totals {             /* device-resident totals of one run */
 	unsigned long long counters[8];   /* iexit, not_entered, not_transmitted, sum_irefl, failed_slots, launches */
+	unsigned long long phase[8];      /* scheduler statistics: march steps, march lane-steps, event phases, event lanes, new phases, new lanes */
 	unsigned long long next_slot;     /* work counter (relative slot index) */
 	unsigned long long pad;
 	/* followed by 2*n_energies u64: (lo, hi) fixed-point weight sums */
 };
 
 struct pc_kargs {
-	const double *g_z, *g_cap, *g_zh, *g_cap2, *g_hexd, *g_ext;
+	const double *g_z, *g_cap, *g_zh, *g_cap2, *g_hexd, *g_idz, *g_ext;
 	const pc_energy_const *ec;
 	pc_params pm;
 	unsigned long long seed;
@@ -59,7 +63,9 @@ struct pc_kargs {
 	int march_burst;
 	pc_totals *totals;
 	unsigned long long *sumw;     /* 2*n_energies */
-	pc_img_planes img;
+	double *img;                  /* [n_slots][17 + n_energies] records, or NULL */
+	int new_threshold;
+	int pad1;
 	double *wscratch;             /* NE==0: n_energies * total_threads */
 	long long total_threads;
 	/* explicit-photon mode */
@@ -95,23 +101,25 @@ __device__ __forceinline__ void pc_atomic_add128(unsigned long long *lohi, unsig
 enum { PC_MODE_SRC_CIRCULAR = 0, PC_MODE_SRC_GENERIC = 1, PC_MODE_EXPLICIT = 2 };
 
 template <int NE, int MODE>
-__global__ void __launch_bounds__(PC_BLOCK)
+__global__ void __launch_bounds__(PC_BLOCK, PC_MIN_WAVES)
 pc_trace_kernel(pc_kargs a)
 {
 	constexpr bool EXPLICIT = (MODE == PC_MODE_EXPLICIT);
 	extern __shared__ double lds[];
 	const int npts = a.pm.nmax + 1;
-	double *l_z = lds, *l_cap = lds + npts, *l_zh = lds + 2*npts, *l_cap2 = lds + 3*npts, *l_hexd = lds + 4*npts;
+	double *l_z = lds, *l_cap = lds + npts, *l_zh = lds + 2*npts, *l_cap2 = lds + 3*npts, *l_hexd = lds + 4*npts, *l_idz = lds + 5*npts;
 	for (int k = threadIdx.x; k < npts; k += blockDim.x) {
 		l_z[k] = a.g_z[k];
 		l_cap[k] = a.g_cap[k];
 		l_zh[k] = a.g_zh[k];
 		l_cap2[k] = a.g_cap2[k];
 		l_hexd[k] = a.g_hexd[k];
+		l_idz[k] = a.g_idz[k];
 	}
 	__syncthreads();
 	pc_tables T;
-	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.hexd = l_hexd; T.ext = a.g_ext;
+	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.hexd = l_hexd; T.idz = l_idz; T.ext = a.g_ext;
+	const long long rec = PC_N_FIELDS + (long long)a.pm.n_energies;   /* doubles per image record */
 	const pc_params &Pm = a.pm;
 	const int ne = (NE > 0) ? NE : Pm.n_energies;
 	const int lane = threadIdx.x & (PC_WAVE - 1);
@@ -135,6 +143,9 @@ pc_trace_kernel(pc_kargs a)
 #pragma unroll
 	for (int e = 0; e < (NE > 0 ? NE : 1); e++) { acc_lo[e] = 0; acc_hi[e] = 0; }
 
+	/* wave-uniform scheduler statistics (diagnostics: lane utilisation per phase type) */
+	unsigned long long st_march = 0, st_march_l = 0, st_event = 0, st_event_l = 0, st_new = 0, st_new_l = 0;
+
 	for (;;) {
 		const unsigned long long mM = __ballot(state == LS_MARCH);
 		const unsigned long long mE = __ballot(state == LS_EVENT);
@@ -142,18 +153,27 @@ pc_trace_kernel(pc_kargs a)
 		if ((mM | mE | mN) == 0ull) break;
 		const int nM = __popcll(mM), nE = __popcll(mE), nN = __popcll(mN);
 
-		if (nM > 0 && (nM >= a.event_threshold || (nE == 0 && nN == 0))) {
+		/* NEW is worth a phase once enough lanes wait for it, or when nothing else can run */
+		const bool do_new = (nN >= a.new_threshold) || (nM == 0 && nE == 0);
+		if (nM > 0 && (nM >= a.event_threshold || (nE == 0 && !do_new))) {
 			/* ---------------- MARCH burst: certified node skipping, 6 FMA + 3 LDS reads per node */
 			for (int b = 0; b < a.march_burst; b++) {
-				if (state == LS_MARCH)
-					state = pc_march_step(T, Pm, ph);
-				if (__popcll(__ballot(state == LS_MARCH)) < a.event_threshold) break;
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+					if (state == LS_MARCH)
+						state = pc_march_step(T, Pm, ph);
+				const int cM = __popcll(__ballot(state == LS_MARCH));
+				st_march += 4; st_march_l += 4*(unsigned)cM;
+				if (cM == 0) break;
+				if (cM < a.event_threshold && (cM != nM || do_new || nE > 0)) break;
 			}
-		} else if (nE > 0 && nE >= nN) {
+		} else if (nE > 0 && !(do_new && nN > nE)) {
 			/* ---------------- EVENT: full quadratic of one segment (+ wall hit, Fresnel reflection) */
+			st_event += 1; st_event_l += (unsigned)nE;
 			if (state == LS_EVENT)
 				state = pc_event(T, Pm, a.ec, ph);
-		} else if (nN > 0) {
+		} else if (nN > 0 && do_new) {
+			st_new += 1; st_new_l += (unsigned)nN;
 			/* ---------------- NEW: finalise finished photons, hand out slots, sample + entrance tests */
 			if (state == LS_DONE) {
 				const int rc = ph.rc;
@@ -187,21 +207,21 @@ pc_trace_kernel(pc_kargs a)
 							} else {
 								pc_atomic_add128(a.sumw + 2*e, f, 0ull);
 							}
-							if (a.keep_images) a.img.weights[slot*ne + e] = w;
+							if (a.keep_images) a.img[slot*rec + PC_F_WEIGHTS + e] = w;
 						}
 						if (a.keep_images) {
 							/* src/polycap-source.c:900-923 */
-							const long long j = slot;
+							double *r = a.img + slot*rec;
 							double t = (Pm.z_end - ph.Pz) / ph.dz;
 							double ex = ph.Px + ph.dx*t, ey = ph.Py + ph.dy*t, ez = ph.Pz + ph.dz*t;
-							a.img.pc_exit[0][j] = ex; a.img.pc_exit[1][j] = ey; a.img.pc_exit[2][j] = ez;
-							a.img.pc_exit_dir[0][j] = ph.dx; a.img.pc_exit_dir[1][j] = ph.dy;
+							r[PC_F_EXITX] = ex; r[PC_F_EXITY] = ey; r[PC_F_EXITZ] = ez;
+							r[PC_F_EDIRX] = ph.dx; r[PC_F_EDIRY] = ph.dy;
 							double tx = ph.ex*c_ae + ph.dx*c_be, ty = ph.ey*c_ae + ph.dy*c_be, tz = ph.ez*c_ae + ph.dz*c_be;
 							pc_norm3(tx, ty, tz);
-							a.img.pc_exit_elecv[0][j] = round(tx); a.img.pc_exit_elecv[1][j] = round(ty);
-							a.img.nrefl[j] = ph.irefl;
+							r[PC_F_EEVX] = round(tx); r[PC_F_EEVY] = round(ty);
+							((long long *)r)[PC_F_NREFL] = ph.irefl;
 							double lx = ex - ph.Px, ly = ey - ph.Py, lz = Pm.z_end - ph.Pz;
-							a.img.dtravel[j] = ph.dtravel + sqrt(lx*lx + ly*ly + lz*lz);
+							r[PC_F_DTRAVEL] = ph.dtravel + sqrt(lx*lx + ly*ly + lz*lz);
 						}
 						state = LS_NEED_SLOT;
 					} else {
@@ -209,7 +229,7 @@ pc_trace_kernel(pc_kargs a)
 						if (attempt >= a.max_attempts) {
 							n_failed++;
 							if (a.keep_images)
-								for (int e = 0; e < ne; e++) a.img.weights[slot*ne + e] = 0.;
+								for (int e = 0; e < ne; e++) a.img[slot*rec + PC_F_WEIGHTS + e] = 0.;
 							state = LS_NEED_SLOT;
 						} else {
 							state = LS_START;
@@ -264,22 +284,17 @@ pc_trace_kernel(pc_kargs a)
 						c_ae = 1.0 / sqrt(1.0 - cosalpha*cosalpha);
 						c_be = -1.*c_ae*cosalpha;
 						if (a.keep_images) {
-							const long long j = slot;
-							a.img.src_start[0][j] = s.srcx; a.img.src_start[1][j] = s.srcy;
-							a.img.pc_start[0][j] = s.x; a.img.pc_start[1][j] = s.y;
-							a.img.pc_start_dir[0][j] = s.dx; a.img.pc_start_dir[1][j] = s.dy;
+							double *r = a.img + slot*rec;
+							r[PC_F_SRCX] = s.srcx; r[PC_F_SRCY] = s.srcy;
+							r[PC_F_STARTX] = s.x; r[PC_F_STARTY] = s.y;
+							r[PC_F_SDIRX] = s.dx; r[PC_F_SDIRY] = s.dy;
 							double tx = s.ex*c_ae + s.dx*c_be, ty = s.ey*c_ae + s.dy*c_be, tz = s.ez*c_ae + s.dz*c_be;
 							pc_norm3(tx, ty, tz);
-							a.img.pc_start_elecv[0][j] = round(tx); a.img.pc_start_elecv[1][j] = round(ty);
+							r[PC_F_SEVX] = round(tx); r[PC_F_SEVY] = round(ty);
 						}
 					}
 				}
 			}
-		} else {
-			/* nM > 0 but below the threshold and nothing else pending is handled by the first branch;
-			 * reaching here means only MARCH lanes below threshold with events pending < new: run events/new next */
-			if (state == LS_EVENT)
-				state = pc_event(T, Pm, a.ec, ph);
 		}
 	}
 
@@ -294,6 +309,9 @@ pc_trace_kernel(pc_kargs a)
 			atomicAdd(&a.totals->counters[3], v3);
 			if (v4) atomicAdd(&a.totals->counters[4], v4);
 			atomicAdd(&a.totals->counters[5], v5);
+			atomicAdd(&a.totals->phase[0], st_march); atomicAdd(&a.totals->phase[1], st_march_l);
+			atomicAdd(&a.totals->phase[2], st_event); atomicAdd(&a.totals->phase[3], st_event_l);
+			atomicAdd(&a.totals->phase[4], st_new); atomicAdd(&a.totals->phase[5], st_new_l);
 		}
 		if (NE > 0) {
 #pragma unroll
@@ -326,6 +344,20 @@ __global__ void pc_sample_kernel(pc_params pm, unsigned long long seed, long lon
 	o[6] = s.ex; o[7] = s.ey; o[8] = s.ez; o[9] = s.srcx; o[10] = s.srcy; o[11] = 0.;
 }
 
+/* image records [first, first+count) -> SoA planes (plane k at out + k*count; weights row-major behind them) */
+__global__ void pc_images_transpose_kernel(const double *img, long long rec, long long first, long long count, int ne, double *out)
+{
+	long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= count) return;
+	const double *r = img + (first + j)*rec;
+#pragma unroll
+	for (int k = 0; k < PC_N_FIELDS; k++)
+		out[(long long)k*count + j] = r[k];
+	double *w = out + (long long)PC_N_FIELDS*count + j*ne;
+	for (int e = 0; e < ne; e++)
+		w[e] = r[PC_F_WEIGHTS + e];
+}
+
 /* =========================================================================== host side (C-ABI) */
 
 static thread_local std::string g_last_error;
@@ -345,17 +377,21 @@ struct pc_hip_ctx {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	pc_host_tables host;
-	double *d_tables = nullptr;            /* z, cap, zh, cap2, hexd, ext: 6 x npts */
+	double *d_tables = nullptr;            /* z, cap, zh, cap2, hexd, idz, ext: 7 x npts */
 	pc_energy_const *d_ec = nullptr;
 	/* options */
 	int literal = 0;
-	int event_threshold = 40;
-	int march_burst = 64;
-	int blocks_per_cu = 4;
+	int event_threshold = 24;      /* tuned on MI355X, xos1 10 keV: scripts/ab_bench.sh */
+	int new_threshold = 4;
+	int march_burst = 16;
+	int blocks_per_cu = 2;
+	int block_size = 512;
 	/* last run */
 	pc_totals *d_totals = nullptr;         /* pc_totals + 2*nE u64 */
 	size_t totals_bytes = 0;
-	double *d_img = nullptr;               /* 17 planes x n_slots (+ weights) */
+	double *d_img = nullptr;               /* image records: n_slots x (17 + n_energies) doubles */
+	double *d_stage = nullptr;             /* SoA staging buffer for image fetches */
+	size_t stage_elems = 0;
 	long long img_slots = 0;
 	int img_valid = 0;
 	double *d_wscratch = nullptr;
@@ -370,11 +406,13 @@ static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
 	const size_t npts = (size_t)ctx->host.pm.nmax + 1;
 	memset(&a, 0, sizeof(a));
 	a.g_z = ctx->d_tables; a.g_cap = ctx->d_tables + npts; a.g_zh = ctx->d_tables + 2*npts;
-	a.g_cap2 = ctx->d_tables + 3*npts; a.g_hexd = ctx->d_tables + 4*npts; a.g_ext = ctx->d_tables + 5*npts;
+	a.g_cap2 = ctx->d_tables + 3*npts; a.g_hexd = ctx->d_tables + 4*npts; a.g_idz = ctx->d_tables + 5*npts;
+	a.g_ext = ctx->d_tables + 6*npts;
 	a.ec = ctx->d_ec;
 	a.pm = ctx->host.pm;
 	a.pm.literal = ctx->literal;
 	a.event_threshold = ctx->event_threshold;
+	a.new_threshold = ctx->new_threshold;
 	a.march_burst = ctx->march_burst;
 	a.totals = ctx->d_totals;
 	a.sumw = (unsigned long long *)(ctx->d_totals + 1);
@@ -384,7 +422,7 @@ template <int NE, int MODE>
 static int pc_launch_one(pc_hip_ctx *ctx, const pc_kargs &a, int grid, size_t lds_bytes)
 {
 	PC_HIP_CHECK(hipFuncSetAttribute((const void *)pc_trace_kernel<NE, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-	hipLaunchKernelGGL((pc_trace_kernel<NE, MODE>), dim3(grid), dim3(PC_BLOCK), lds_bytes, ctx->stream, a);
+	hipLaunchKernelGGL((pc_trace_kernel<NE, MODE>), dim3(grid), dim3(ctx->block_size), lds_bytes, ctx->stream, a);
 	PC_HIP_CHECK(hipGetLastError());
 	return PC_HIP_OK;
 }
@@ -394,12 +432,13 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 {
 	const int ne = ctx->host.pm.n_energies;
 	const size_t npts = (size_t)ctx->host.pm.nmax + 1;
-	const size_t lds_bytes = 5*npts*sizeof(double);
+	const size_t lds_bytes = 6*npts*sizeof(double);
 	long long max_blocks = (long long)ctx->n_cu * ctx->blocks_per_cu;
-	long long want_blocks = (n_items + PC_BLOCK - 1) / PC_BLOCK;
+	const int block = ctx->block_size;
+	long long want_blocks = (n_items + block - 1) / block;
 	int grid = (int)(want_blocks < max_blocks ? want_blocks : max_blocks);
 	if (grid < 1) grid = 1;
-	a.total_threads = (long long)grid * PC_BLOCK;
+	a.total_threads = (long long)grid * block;
 	if (ne != 1) {
 		size_t need = (size_t)ne * (size_t)a.total_threads;
 		if (need > ctx->wscratch_elems) {
@@ -441,6 +480,7 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->d_ec) (void)hipFree(ctx->d_ec);
 	if (ctx->d_totals) (void)hipFree(ctx->d_totals);
 	if (ctx->d_img) (void)hipFree(ctx->d_img);
+	if (ctx->d_stage) (void)hipFree(ctx->d_stage);
 	if (ctx->d_wscratch) (void)hipFree(ctx->d_wscratch);
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -461,7 +501,7 @@ int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ou
 	int rc = pc_build_tables(problem, ctx->host, err);
 	if (rc) { delete ctx; return pc_fail(rc, "pc_hip_ctx_create: " + err); }
 	const size_t npts = (size_t)ctx->host.pm.nmax + 1;
-	if (5*npts*sizeof(double) > 160*1024) { delete ctx; return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_ctx_create: profile too long for the 160 KB LDS (nmax <= 4095)"); }
+	if (6*npts*sizeof(double) > 160*1024) { delete ctx; return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_ctx_create: profile too long for the 160 KB LDS (nmax <= 3412)"); }
 #define PC_CTX_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); pc_hip_ctx_destroy(ctx); return pc_fail(PC_HIP_ERR_RUNTIME, m); } } while (0)
 	PC_CTX_CHECK(hipSetDevice(device));
 	hipDeviceProp_t prop;
@@ -470,9 +510,9 @@ int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ou
 	PC_CTX_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
 	PC_CTX_CHECK(hipEventCreate(&ctx->ev0));
 	PC_CTX_CHECK(hipEventCreate(&ctx->ev1));
-	PC_CTX_CHECK(hipMalloc(&ctx->d_tables, 6*npts*sizeof(double)));
-	const std::vector<double> *src[6] = { &ctx->host.z, &ctx->host.cap, &ctx->host.zh, &ctx->host.cap2, &ctx->host.hexd, &ctx->host.ext };
-	for (int k = 0; k < 6; k++)
+	PC_CTX_CHECK(hipMalloc(&ctx->d_tables, 7*npts*sizeof(double)));
+	const std::vector<double> *src[7] = { &ctx->host.z, &ctx->host.cap, &ctx->host.zh, &ctx->host.cap2, &ctx->host.hexd, &ctx->host.idz, &ctx->host.ext };
+	for (int k = 0; k < 7; k++)
 		PC_CTX_CHECK(hipMemcpy(ctx->d_tables + k*npts, src[k]->data(), npts*sizeof(double), hipMemcpyHostToDevice));
 	PC_CTX_CHECK(hipMalloc(&ctx->d_ec, ctx->host.ec.size()*sizeof(pc_energy_const)));
 	PC_CTX_CHECK(hipMemcpy(ctx->d_ec, ctx->host.ec.data(), ctx->host.ec.size()*sizeof(pc_energy_const), hipMemcpyHostToDevice));
@@ -490,7 +530,9 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	std::string n(name);
 	if (n == "literal_march") ctx->literal = value ? 1 : 0;
 	else if (n == "event_threshold") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "event_threshold must be in [1,64]"); ctx->event_threshold = (int)value; }
+	else if (n == "new_threshold") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "new_threshold must be in [1,64]"); ctx->new_threshold = (int)value; }
 	else if (n == "march_burst") { if (value < 1) return pc_fail(PC_HIP_ERR_INVALID, "march_burst must be >= 1"); ctx->march_burst = (int)value; }
+	else if (n == "block_size") { if (value != 64 && value != 128 && value != 256 && value != 512) return pc_fail(PC_HIP_ERR_INVALID, "block_size must be 64, 128, 256 or 512"); ctx->block_size = (int)value; }
 	else if (n == "blocks_per_cu") { if (value < 1 || value > 8) return pc_fail(PC_HIP_ERR_INVALID, "blocks_per_cu must be in [1,8]"); ctx->blocks_per_cu = (int)value; }
 	else return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_set_option: unknown option " + n);
 	return PC_HIP_OK;
@@ -597,18 +639,7 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 				return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_run: could not allocate the image planes; use keep_images=0");
 			ctx->img_slots = n_slots;
 		}
-		double *p = ctx->d_img;
-		const size_t S = (size_t)ctx->img_slots;
-		a.img.src_start[0] = p; a.img.src_start[1] = p + S;
-		a.img.pc_start[0] = p + 2*S; a.img.pc_start[1] = p + 3*S;
-		a.img.pc_start_dir[0] = p + 4*S; a.img.pc_start_dir[1] = p + 5*S;
-		a.img.pc_start_elecv[0] = p + 6*S; a.img.pc_start_elecv[1] = p + 7*S;
-		a.img.pc_exit[0] = p + 8*S; a.img.pc_exit[1] = p + 9*S; a.img.pc_exit[2] = p + 10*S;
-		a.img.pc_exit_dir[0] = p + 11*S; a.img.pc_exit_dir[1] = p + 12*S;
-		a.img.pc_exit_elecv[0] = p + 13*S; a.img.pc_exit_elecv[1] = p + 14*S;
-		a.img.nrefl = (long long *)(p + 15*S);
-		a.img.dtravel = p + 16*S;
-		a.img.weights = p + 17*S;
+		a.img = ctx->d_img;
 	}
 	PC_HIP_CHECK(hipMemsetAsync(ctx->d_totals, 0, ctx->totals_bytes, ctx->stream));
 	a.seed = seed; a.slot0 = slot0; a.n_slots = n_slots; a.max_attempts = max_attempts; a.keep_images = keep_images ? 1 : 0;
@@ -663,6 +694,17 @@ int pc_hip_transmission_totals(pc_hip_ctx *ctx, double *sum_weights, int64_t cou
 	return PC_HIP_OK;
 }
 
+int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6])
+{
+	if (!ctx || !stats) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_phase_stats: NULL argument");
+	int st = pc_hip_transmission_wait(ctx, nullptr);
+	if (st) return st;
+	pc_totals t;
+	PC_HIP_CHECK(hipMemcpy(&t, ctx->d_totals, sizeof(t), hipMemcpyDeviceToHost));
+	for (int k = 0; k < 6; k++) stats[k] = (int64_t)t.phase[k];
+	return PC_HIP_OK;
+}
+
 int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const pc_hip_images *dst)
 {
 	if (!ctx || !dst) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: NULL argument");
@@ -671,19 +713,36 @@ int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, co
 	int st = pc_hip_transmission_wait(ctx, nullptr);
 	if (st) return st;
 	if (count == 0) return PC_HIP_OK;
-	const size_t S = (size_t)ctx->img_slots, ne = (size_t)ctx->host.pm.n_energies;
-	const double *p = ctx->d_img;
+	const size_t ne = (size_t)ctx->host.pm.n_energies, rec = (size_t)PC_N_PLANES + ne;
 	void *planes[PC_N_PLANES] = {
 		dst->src_start_coords[0], dst->src_start_coords[1], dst->pc_start_coords[0], dst->pc_start_coords[1],
 		dst->pc_start_dir[0], dst->pc_start_dir[1], dst->pc_start_elecv[0], dst->pc_start_elecv[1],
 		dst->pc_exit_coords[0], dst->pc_exit_coords[1], dst->pc_exit_coords[2],
 		dst->pc_exit_dir[0], dst->pc_exit_dir[1], dst->pc_exit_elecv[0], dst->pc_exit_elecv[1],
 		dst->pc_exit_nrefl, dst->pc_exit_dtravel };
-	for (int k = 0; k < PC_N_PLANES; k++)
-		if (planes[k])
-			PC_HIP_CHECK(hipMemcpy(planes[k], p + (size_t)k*S + (size_t)first, (size_t)count*sizeof(double), hipMemcpyDeviceToHost));
-	if (dst->exit_coord_weights)
-		PC_HIP_CHECK(hipMemcpy(dst->exit_coord_weights, p + 17*S + (size_t)first*ne, (size_t)count*ne*sizeof(double), hipMemcpyDeviceToHost));
+	/* records -> SoA planes on the device, in chunks of <= 256 MB, then plane-wise D2H copies */
+	size_t chunk = (size_t)(256u << 20) / (rec*sizeof(double));
+	if (chunk < 1024) chunk = 1024;
+	if (chunk > (size_t)count) chunk = (size_t)count;
+	if (ctx->stage_elems < chunk*rec) {
+		if (ctx->d_stage) PC_HIP_CHECK(hipFree(ctx->d_stage));
+		ctx->d_stage = nullptr; ctx->stage_elems = 0;
+		if (hipMalloc(&ctx->d_stage, chunk*rec*sizeof(double)) != hipSuccess)
+			return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_images: could not allocate the staging buffer");
+		ctx->stage_elems = chunk*rec;
+	}
+	for (size_t done = 0; done < (size_t)count; done += chunk) {
+		const size_t n = ((size_t)count - done < chunk) ? (size_t)count - done : chunk;
+		hipLaunchKernelGGL(pc_images_transpose_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, ctx->stream,
+		                   ctx->d_img, (long long)rec, (long long)(first + (int64_t)done), (long long)n, (int)ne, ctx->d_stage);
+		PC_HIP_CHECK(hipGetLastError());
+		PC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		for (int k = 0; k < PC_N_PLANES; k++)
+			if (planes[k])
+				PC_HIP_CHECK(hipMemcpy((char *)planes[k] + done*sizeof(double), ctx->d_stage + (size_t)k*n, n*sizeof(double), hipMemcpyDeviceToHost));
+		if (dst->exit_coord_weights)
+			PC_HIP_CHECK(hipMemcpy(dst->exit_coord_weights + done*ne, ctx->d_stage + (size_t)PC_N_PLANES*n, n*ne*sizeof(double), hipMemcpyDeviceToHost));
+	}
 	return PC_HIP_OK;
 }
 

@@ -5,6 +5,7 @@
  *   zh[i]   = ext[i] / (2 cos(pi/6) (n_shells+1))     hex-grid pitch: capillary axis = (kx,ky)*zh[i]
  *                                                     (reference src/polycap-photon.c:624-627)
  *   cap2[i] = cap[i]^2
+ *   idz[i]  = 1 / (z[i+1] - z[i])
  *   hexd[i] = sqrt(ext^2 - (ext/2)^2)                 centre-to-edge distance of the outer hexagon
  *                                                     (reference src/polycap-photon.c:158)
  * Per-energy constants: complex refractive index n = (1-alfa) + i beta and (1/n)^2
@@ -26,7 +27,7 @@
 #define PC_R0     2.8179403227e-13
 
 struct pc_host_tables {
-	std::vector<double> z, cap, zh, cap2, hexd, ext;
+	std::vector<double> z, cap, zh, cap2, hexd, idz, ext;
 	std::vector<pc_energy_const> ec;
 	pc_params pm;
 };
@@ -65,7 +66,7 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 	t.z.assign(p->z, p->z + n);
 	t.cap.assign(p->cap, p->cap + n);
 	t.ext.assign(p->ext, p->ext + n);
-	t.zh.resize(n); t.cap2.resize(n); t.hexd.resize(n);
+	t.zh.resize(n); t.cap2.resize(n); t.hexd.resize(n); t.idz.assign(n, 0.);
 	double dr2max = 0., capmin = HUGE_VAL, capmax = 0., extmax = 0., ratio = 0.;
 	for (int i = 0; i < n; i++) {
 		double e = p->ext[i], c = p->cap[i];
@@ -73,6 +74,7 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 		t.cap2[i] = c*c;
 		t.hexd[i] = (e > 0.) ? std::sqrt(e*e - (e/2.)*(e/2.)) : 0.;
 		if (i + 1 < n) {
+			t.idz[i] = 1.0 / (p->z[i+1] - p->z[i]);
 			double dr = p->cap[i+1] - c;
 			if (dr*dr > dr2max) dr2max = dr*dr;
 		}

@@ -122,6 +122,16 @@ class TraceContext:
                     i_exit=int(cnt[0]), not_entered=int(cnt[1]), not_transmitted=int(cnt[2]), sum_irefl=int(cnt[3]),
                     failed_slots=int(cnt[4]), launches=int(cnt[5]), i_start=int(cnt[0] + cnt[1] + cnt[2]))
 
+    def phase_stats(self):
+        """Average active lanes per scheduler phase of the last run (diagnostics)."""
+        st = np.zeros(6, dtype=np.int64)
+        rc = self._L.pc_hip_phase_stats(self._h, st.ctypes.data_as(c_int64_p))
+        if rc != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_phase_stats", rc)
+        names = ("march", "event", "new")
+        return {n: dict(phases=int(st[2 * i]), lanes=int(st[2 * i + 1]),
+                        avg_lanes=float(st[2 * i + 1]) / max(1, int(st[2 * i]))) for i, n in enumerate(names)}
+
     def images(self, first=0, count=None):
         count = self._last_n - first if count is None else count
         ne = self.problem.n_energies

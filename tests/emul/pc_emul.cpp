@@ -27,7 +27,7 @@ int setup(const pc_hip_problem *p, int literal, Emul &E)
 	if (rc) return rc;
 	E.t.pm.literal = literal;
 	E.T.z = E.t.z.data(); E.T.cap = E.t.cap.data(); E.T.zh = E.t.zh.data();
-	E.T.cap2 = E.t.cap2.data(); E.T.hexd = E.t.hexd.data(); E.T.ext = E.t.ext.data();
+	E.T.cap2 = E.t.cap2.data(); E.T.hexd = E.t.hexd.data(); E.T.idz = E.t.idz.data(); E.T.ext = E.t.ext.data();
 	return 0;
 }
 

@@ -146,11 +146,13 @@ def test_transmission_driver_vs_oracle(pa, oracle, known):
     assert g["i_exit"] == n and g["failed_slots"] == 0
     # the reference's published known answer (tests/source.c:218): 0.135 +- 0.0075 at 10 keV
     assert abs(g["efficiencies"][0] - 0.135) <= 0.0075
-    # same seed, same slots: counters and efficiency agree within the chaos floor (c/sqrt(N), c = 1.0)
-    tol = 1.0 / np.sqrt(g["i_start"])
+    # same seed, same slots.  Photons whose trajectories decorrelate (chaos) also change the retry sequence of their
+    # slot, so i_start (sum of ~geometric attempt counts, variance ~4 per slot) and the efficiency differ by
+    # ~1/sqrt(i_start) (1 sigma); tolerance 4/sqrt(i_start)
+    tol = 4.0 / np.sqrt(g["i_start"])
     assert abs(g["i_start"] - o["i_start"]) / o["i_start"] < tol
     assert abs(g["efficiencies"][0] - o["efficiencies"][0]) / o["efficiencies"][0] < tol
-    assert abs(g["sum_irefl"] - o["sum_irefl"]) / o["sum_irefl"] < 3 * tol
+    assert abs(g["sum_irefl"] - o["sum_irefl"]) / o["sum_irefl"] < tol
     # totals are consistent with the per-slot planes
     assert np.isclose(g["exit_weights"].sum(), g["sum_weights"][0], rtol=1e-12)
     assert g["nrefl"].sum() == g["sum_irefl"]
