@@ -143,6 +143,15 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "fp64-VALU/divergence-bound by construction (SURVEY 8d): 144 B per exit photon"},
         }
+        if keep_images and world == 1:
+            # not part of `value`: the same step plus the copy of all image planes to host memory (PCIe)
+            t1 = time.perf_counter()
+            ctx.run(args.seed, slot0, n_local, keep_images=True)
+            ctx.wait()
+            tt = ctx.totals()
+            ctx.images(0, n_local)
+            dt = time.perf_counter() - t1
+            out["pcie_inclusive_photons_per_s"] = tt["i_start"] / dt
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob, args, ctx)
         print(json.dumps(out), flush=True)

@@ -44,6 +44,10 @@ def unpack_totals(vec):
 
 def allreduce_totals(vec, device=None):
     """Sum the packed totals over all ranks (no-op without an initialised process group)."""
+    import os
+    import sys
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and "torch.distributed" not in sys.modules:
+        return np.asarray(vec, dtype=np.int64)      # single process: do not even import torch
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

@@ -192,6 +192,17 @@ def test_partition_invariance_and_reproducibility(pa, oracle):
     assert (lo & (2**64 - 1), hi) == (int(a["sumw_fixed"][0, 0]), int(a["sumw_fixed"][0, 1]))
 
 
+def test_run_sharded_single_rank_uses_the_kernel(pa, oracle):
+    from polycap_amd import distributed as pcd
+    optic, src, prob, _ = make_pair(oracle, "xos1", source=(2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.0))
+    r = pcd.run_sharded(prob, 5, 30000)
+    with pa.TraceContext(prob) as ctx:
+        t = ctx.transmission(5, 0, 30000)
+    assert r["counters"][:4].tolist() == t["counters"][:4].tolist()
+    assert r["sumw_exact"][0] == int(t["sumw_fixed"][0, 0]) + (int(t["sumw_fixed"][0, 1]) << 64)
+    assert np.array_equal(r["efficiencies"], t["efficiencies"])
+
+
 def test_multi_energy_and_roughness(pa, oracle):
     """n_energies > 1 (weights in memory) and sig_rough > 0 (exp path): kernel vs oracle on identical photons."""
     energies = np.linspace(5.0, 20.0, 7)
