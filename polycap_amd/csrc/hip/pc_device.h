@@ -491,11 +491,11 @@ PC_HD int pc_segment(const pc_tables &T, const pc_photon<NE> &ph, int i,
 	double discr = fma(b, b, -4.*a*c);
 	if (discr < 0) return -2;
 	double last = ph.Pz;
+	const double i2a = 1.0/(2.*a);
 	if (discr == 0) {
-		hz = z0 + (-1.*b)/(2.*a);
+		hz = z0 + (-1.*b)*i2a;
 	} else {
 		double sq = sqrt(discr);
-		double i2a = 1.0/(2.*a);
 		double zr1 = z0 + (-1.*b + sq)*i2a;
 		double zr2 = z0 + (-1.*b - sq)*i2a;
 		/* written as negated "valid" tests so NaN behaves as in the reference (all comparisons false) */
@@ -520,18 +520,27 @@ PC_HD int pc_segment(const pc_tables &T, const pc_photon<NE> &ph, int i,
 	double s1 = fma(qx, cdx, qy*cdy);                              /* (phot0-cap0).cap_dir, z component is 0 */
 	double s2 = fma(ph.dx, cdx, fma(ph.dy, cdy, ph.dz*cdz));       /* photon_dir.cap_dir */
 	double s3 = fma(cdx, cdx, fma(cdy, cdy, cdz*cdz));             /* |cap_dir|^2 */
-	double tpar = fma(d_proj, s2, s1) / s3;
+	double is3 = 1.0 / s3;
+	double tpar = fma(d_proj, s2, s1) * is3;
 	double inx = hx - fma(tpar, cdx, c0x);
 	double iny = hy - fma(tpar, cdy, c0y);
 	double inz = hz - fma(tpar, cdz, z0);
 	double idci = 1.0 / sqrt(fma(inx, inx, fma(iny, iny, inz*inz)));
-	double tg = -dR / s3;                                           /* tan(gamma)/|cap_dir| */
+	double tg = -dR * is3;                                          /* tan(gamma)/|cap_dir| */
 	/* n ~ in/|in| + tan(gamma) * cap_dir/|cap_dir|, normalised once (= cos(gamma) in/|in| + sin(gamma) cap_dir/|cap_dir|
 	 * of the reference up to its own final normalisation) */
 	nx = fma(inx, idci, tg*cdx);
 	ny = fma(iny, idci, tg*cdy);
 	nz = fma(inz, idci, tg*cdz);
-	pc_norm3(nx, ny, nz);
+	/* |n|^2 = 1 + eps with eps ~ tan^2(gamma) + 2 tan(gamma) u.c: 1/sqrt(1+eps) by its series when eps is tiny
+	 * (truncation < eps^4), by sqrt otherwise */
+	double eps = fma(nx, nx, fma(ny, ny, nz*nz)) - 1.0;
+	double f;
+	if (fabs(eps) < 1e-4)
+		f = fma(eps, fma(eps, fma(eps, -0.3125, 0.375), -0.5), 1.0);
+	else
+		f = 1.0 / sqrt(1.0 + eps);
+	nx *= f; ny *= f; nz *= f;
 	return 1;
 }
 
@@ -555,8 +564,9 @@ PC_HD int pc_reflect(const pc_params &Pm, const pc_energy_const *EC, pc_photon<N
 	double sdy = fma(nz, ph.dx, -ph.dz*nx);
 	double sdz = fma(nx, ph.dy, -ph.dx*ny);
 	double es = fma(ph.ex, sdx, fma(ph.ey, sdy, ph.ez*sdz));
-	double frac_s = (es*es) / fma(sdx, sdx, fma(sdy, sdy, sdz*sdz));
-	double frac_p = 1. - frac_s;
+	double es2 = es*es;                                         /* frac_s = es2/sd2, frac_p = (sd2-es2)/sd2 */
+	double sd2 = fma(sdx, sdx, fma(sdy, sdy, sdz*sdz));
+	double ep2 = sd2 - es2;
 
 	int keep = 0;
 	const int ne = (NE > 0) ? NE : Pm.n_energies;
@@ -566,16 +576,13 @@ PC_HD int pc_reflect(const pc_params &Pm, const pc_energy_const *EC, pc_photon<N
 		/* tmp = n_inv^2 * sin^2 ; csq = csqrt(1 - tmp)   (:503-505) */
 		double wr = fma(-ec.ninv2_re, st2, 1.0);
 		double wi = -ec.ninv2_im*st2;
+		/* principal complex square root without cancellation: t = sqrt((|w|+|wr|)/2), u = |wi|/(2t);
+		 * (csr, |csi|) = (t, u) for wr >= 0 and (u, t) for wr < 0; the imaginary part takes the sign of wi */
 		double mag = sqrt(fma(wr, wr, wi*wi));
-		double csr, csi;
-		if (wr >= 0.) {
-			csr = sqrt(0.5*(mag + wr));
-			csi = (csr > 0.) ? wi/(2.*csr) : 0.;
-		} else {
-			double sa = sqrt(0.5*(mag - wr));
-			csr = fabs(wi)/(2.*sa);
-			csi = copysign(sa, wi);
-		}
+		double tt = sqrt(0.5*(mag + fabs(wr)));
+		double uu = (tt > 0.) ? fabs(wi)/(2.*tt) : 0.;
+		double csr = (wr >= 0.) ? tt : uu;
+		double csi = copysign((wr >= 0.) ? uu : tt, wi);
 		/* r_s = (cos - n*csq)/(cos + n*csq)   (:507-510) */
 		double tr = fma(ec.n_re, csr, -ec.n_im*csi);
 		double ti = fma(ec.n_re, csi, ec.n_im*csr);
@@ -585,8 +592,8 @@ PC_HD int pc_reflect(const pc_params &Pm, const pc_energy_const *EC, pc_photon<N
 		double ur = ec.n_re*ct, ui = ec.n_im*ct;
 		double pr = csr - ur, pi_ = csi - ui, er = csr + ur, ei = csi + ui;
 		double Np = fma(pr, pr, pi_*pi_), Dp = fma(er, er, ei*ei);
-		/* rtot = R_s frac_s + R_p frac_p with one division */
-		double rtot = fma(frac_s*Ns, Dp, frac_p*Np*Ds) / (Ds*Dp);
+		/* rtot = R_s frac_s + R_p frac_p = (es2 Ns Dp + ep2 Np Ds) / (sd2 Ds Dp): one division */
+		double rtot = fma(es2*Ns, Dp, ep2*Np*Ds) / (sd2*Ds*Dp);
 		if (rtot < 0. || rtot > 1.) return -1;                  /* :633-637 */
 		double cons1 = ec.rough_c*alfa;                         /* (1.01358*E)*alfa*sig_rough, :626 */
 		double r_rough = (ec.rough_c == 0.) ? 1.0 : exp(-1.*cons1*cons1);
@@ -677,6 +684,14 @@ PC_HD int pc_march_step(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &
 	if (ph.i >= Pm.nmax) { ph.rc = 1; return PC_ST_DONE; }
 	if (Pm.literal) return PC_ST_EVENT;
 	if (ph.first) return pc_march_first_ok(T, Pm, ph) ? PC_ST_MARCH : PC_ST_EVENT;
+	return pc_march_ok(T, Pm, ph) ? PC_ST_MARCH : PC_ST_EVENT;
+}
+
+/* MARCH step of the tight loop: the lane is known not to sit on the first segment of a trace call */
+template <int NE>
+PC_HD int pc_march_step_hot(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph)
+{
+	if (ph.i >= Pm.nmax) { ph.rc = 1; return PC_ST_DONE; }
 	return pc_march_ok(T, Pm, ph) ? PC_ST_MARCH : PC_ST_EVENT;
 }
 

@@ -27,6 +27,7 @@
 
 #define PC_BLOCK 512            /* maximum workgroup size the trace kernel is compiled for */
 #define PC_WAVE 64
+#define PC_MAX_PITCH 2560      /* largest profile kept in static LDS: 6 tables x 2560 x 8 B = 120 KB */
 #define PC_CHUNK 128           /* slots a wave takes from the global counter at a time */
 #define PC_FIX_SCALE 4611686018427387904.0 /* 2^62 */
 #ifndef PC_MIN_WAVES
@@ -100,14 +101,15 @@ __device__ __forceinline__ void pc_atomic_add128(unsigned long long *lohi, unsig
  * source; PC_MODE_SRC_CIRCULAR / _GENERIC: photons are sampled from the source (circular / elliptical). */
 enum { PC_MODE_SRC_CIRCULAR = 0, PC_MODE_SRC_GENERIC = 1, PC_MODE_EXPLICIT = 2 };
 
-template <int NE, int MODE>
+template <int NE, int MODE, int PITCH>
 __global__ void __launch_bounds__(PC_BLOCK, PC_MIN_WAVES)
 pc_trace_kernel(pc_kargs a)
 {
 	constexpr bool EXPLICIT = (MODE == PC_MODE_EXPLICIT);
-	extern __shared__ double lds[];
+	/* static LDS with a compile-time pitch: table reads become ds_read with immediate offsets */
+	__shared__ double lds[6*PITCH];
 	const int npts = a.pm.nmax + 1;
-	double *l_z = lds, *l_cap = lds + npts, *l_zh = lds + 2*npts, *l_cap2 = lds + 3*npts, *l_hexd = lds + 4*npts, *l_idz = lds + 5*npts;
+	double *l_z = lds, *l_cap = lds + PITCH, *l_zh = lds + 2*PITCH, *l_cap2 = lds + 3*PITCH, *l_hexd = lds + 4*PITCH, *l_idz = lds + 5*PITCH;
 	for (int k = threadIdx.x; k < npts; k += blockDim.x) {
 		l_z[k] = a.g_z[k];
 		l_cap[k] = a.g_cap[k];
@@ -157,15 +159,23 @@ pc_trace_kernel(pc_kargs a)
 		const bool do_new = (nN >= a.new_threshold) || (nM == 0 && nE == 0);
 		if (nM > 0 && (nM >= a.event_threshold || (nE == 0 && !do_new))) {
 			/* ---------------- MARCH burst: certified node skipping, 6 FMA + 3 LDS reads per node */
-			for (int b = 0; b < a.march_burst; b++) {
+			if (Pm.literal) {
+				if (state == LS_MARCH)
+					state = pc_march_step(T, Pm, ph);
+			} else {
+				/* lanes fresh from an event or a launch first clear the segment that holds their last interaction point */
+				if (state == LS_MARCH && ph.first)
+					state = pc_march_step(T, Pm, ph);
+				for (int b = 0; b < a.march_burst; b++) {
 #pragma unroll
-				for (int u = 0; u < 4; u++)
-					if (state == LS_MARCH)
-						state = pc_march_step(T, Pm, ph);
-				const int cM = __popcll(__ballot(state == LS_MARCH));
-				st_march += 4; st_march_l += 4*(unsigned)cM;
-				if (cM == 0) break;
-				if (cM < a.event_threshold && (cM != nM || do_new || nE > 0)) break;
+					for (int u = 0; u < 4; u++)
+						if (state == LS_MARCH)
+							state = pc_march_step_hot(T, Pm, ph);
+					const int cM = __popcll(__ballot(state == LS_MARCH));
+					st_march += 4; st_march_l += 4*(unsigned)cM;
+					if (cM == 0) break;
+					if (cM < a.event_threshold && (cM != nM || do_new || nE > 0)) break;
+				}
 			}
 		} else if (nE > 0 && !(do_new && nN > nE)) {
 			/* ---------------- EVENT: full quadratic of one segment (+ wall hit, Fresnel reflection) */
@@ -419,10 +429,13 @@ static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
 }
 
 template <int NE, int MODE>
-static int pc_launch_one(pc_hip_ctx *ctx, const pc_kargs &a, int grid, size_t lds_bytes)
+static int pc_launch_one(pc_hip_ctx *ctx, const pc_kargs &a, int grid)
 {
-	PC_HIP_CHECK(hipFuncSetAttribute((const void *)pc_trace_kernel<NE, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-	hipLaunchKernelGGL((pc_trace_kernel<NE, MODE>), dim3(grid), dim3(ctx->block_size), lds_bytes, ctx->stream, a);
+	/* table pitch: 1024 entries (48 KB of LDS) covers the reference's generated profiles (nmax = 999) and its example decks */
+	if (ctx->host.pm.nmax + 1 <= 1024)
+		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, 1024>), dim3(grid), dim3(ctx->block_size), 0, ctx->stream, a);
+	else
+		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, PC_MAX_PITCH>), dim3(grid), dim3(ctx->block_size), 0, ctx->stream, a);
 	PC_HIP_CHECK(hipGetLastError());
 	return PC_HIP_OK;
 }
@@ -431,8 +444,6 @@ template <int MODE>
 static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 {
 	const int ne = ctx->host.pm.n_energies;
-	const size_t npts = (size_t)ctx->host.pm.nmax + 1;
-	const size_t lds_bytes = 6*npts*sizeof(double);
 	long long max_blocks = (long long)ctx->n_cu * ctx->blocks_per_cu;
 	const int block = ctx->block_size;
 	long long want_blocks = (n_items + block - 1) / block;
@@ -451,7 +462,7 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		a.wscratch = ctx->d_wscratch;
 	}
 	PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
-	int st = (ne == 1) ? pc_launch_one<1, MODE>(ctx, a, grid, lds_bytes) : pc_launch_one<0, MODE>(ctx, a, grid, lds_bytes);
+	int st = (ne == 1) ? pc_launch_one<1, MODE>(ctx, a, grid) : pc_launch_one<0, MODE>(ctx, a, grid);
 	if (st) return st;
 	PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
 	return PC_HIP_OK;
@@ -501,7 +512,7 @@ int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ou
 	int rc = pc_build_tables(problem, ctx->host, err);
 	if (rc) { delete ctx; return pc_fail(rc, "pc_hip_ctx_create: " + err); }
 	const size_t npts = (size_t)ctx->host.pm.nmax + 1;
-	if (6*npts*sizeof(double) > 160*1024) { delete ctx; return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_ctx_create: profile too long for the 160 KB LDS (nmax <= 3412)"); }
+	if (npts > PC_MAX_PITCH) { delete ctx; return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_ctx_create: profile too long for the LDS tables (nmax <= 2559)"); }
 #define PC_CTX_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); pc_hip_ctx_destroy(ctx); return pc_fail(PC_HIP_ERR_RUNTIME, m); } } while (0)
 	PC_CTX_CHECK(hipSetDevice(device));
 	hipDeviceProp_t prop;
