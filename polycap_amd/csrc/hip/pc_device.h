@@ -56,6 +56,7 @@ struct pc_params {
 	double n_shells;
 	double hexscale;    /* 2*cos(pi/6)*(n_shells+1) */
 	double adj;         /* certificate margin: see pc_march_ok */
+	double two_rmax;    /* 2 * max_i cap[i] (block certificates) */
 	double bnd_thresh;  /* max_i cap[i]/ext[i] (+slack): capillaries closer than this to the hexagon edge are "boundary" */
 	double z_end, ext_end;
 	double d_source, src_x, src_y, src_sigx, src_sigy, src_shiftx, src_shifty, frac_hor_pol;
@@ -71,7 +72,12 @@ struct pc_tables {
 	const double *hexd;  /* sqrt(ext^2 - (ext/2)^2): centre-to-edge distance of the outer hexagon at node i */
 	const double *idz;   /* 1 / (z[i+1] - z[i]) */
 	const double *ext;
+	/* block certificates (see pc_march_ok): for stride L1 / L2, margin base and chord deviation of zh, rounded up */
+	const float *mb1, *md1, *mb2, *md2;
 };
+
+#define PC_L1 8     /* strides of the two block-certificate levels, in segments */
+#define PC_L2 32
 
 template <int NE>
 struct pc_photon {
@@ -90,6 +96,8 @@ struct pc_photon {
 	int irefl;
 	int ntrace;             /* completed polycap_capil_trace calls that returned 1 */
 	int first;              /* 1: segment i is the first of a trace call (last hit lies inside it) */
+	int lv;                 /* widest block-certificate stride still allowed on this flight: 0 single segments, 1 L1, 2 L2 */
+	double kn;              /* |(kx, ky)| */
 	int bnd;                /* 1: boundary capillary, hexagon tests are done at every node */
 	int rc;                 /* final polycap_photon_launch return code once DONE */
 };
@@ -287,6 +295,8 @@ PC_HD void pc_trace_begin(pc_photon<NE> &ph)
 	ph.ox = ph.Px - ph.sx * ph.Pz;
 	ph.oy = ph.Py - ph.sy * ph.Pz;
 	ph.first = 1;
+	/* long first flight: start with the widest stride; after a reflection flights are short */
+	ph.lv = ph.bnd ? 0 : ((ph.irefl == 0) ? 2 : 1);
 }
 
 /* src/polycap-photon.c:458-645 + 888-906.  Returns PC_ST_MARCH when the photon entered a capillary,
@@ -337,6 +347,7 @@ PC_HD int pc_launch_init(const pc_tables &T, const pc_params &Pm, pc_photon<NE> 
 	/* :624-627 */
 	ph.ky = r_i * (3./2);
 	ph.kx = (2.*q_i + r_i) * PC_COSPI_6;
+	ph.kn = sqrt(ph.kx*ph.kx + ph.ky*ph.ky);
 	ph.i = (z > 0) ? pc_last_node_le(T, nmax + 1, z) : 0;
 	/* :629-645 */
 	double cur_rad, cur_cx, cur_cy;
@@ -387,24 +398,48 @@ PC_HD int pc_launch_init(const pc_tables &T, const pc_params &Pm, pc_photon<NE> 
 template <int NE>
 PC_HD int pc_march_ok(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph)
 {
-	int i1 = ph.i + 1;
+	/* Block certificate (stride L > 1).  Over nodes i..i+L let zh_c, R_c be the chords of zh and cap between the two
+	 * end nodes, Dzh and DR the largest deviations of the (piecewise linear) tables from those chords, dR = cap[i+L]-cap[i].
+	 * With q = q_c - k*dev_zh and R = R_c + dev_R:
+	 *     g <= g_c + 2 R_max (|k| Dzh + DR) + (|k| Dzh)^2,     g_c <= max(g(z_i), g(z_i+L)) + dR^2/4
+	 * so g < 0 on all L segments when both end values are below -(mb + |k| md (2 R_max + |k| md)), with
+	 * mb = dR^2/4 + 2 R_max DR + m and md = Dzh tabulated per start node (rounded up to float).  L = 1 is the plain
+	 * single-segment certificate with margin adj. */
+	/* ph.lv caps the stride for this flight (lowered after a failed probe); take the widest stride whose margin the
+	 * current node already satisfies */
+	const int cap = ph.lv;
+	const int i0 = ph.i;
+	int lv = 0;
+	double marg = Pm.adj;
+	if (cap >= 1 && i0 + PC_L1 <= Pm.nmax) {
+		double kd = ph.kn * (double)T.md1[i0];
+		double m1 = fma(kd, Pm.two_rmax + kd, (double)T.mb1[i0]);
+		if (ph.C0 < -m1) { lv = 1; marg = m1; }
+	}
+	if (cap >= 2 && i0 + PC_L2 <= Pm.nmax) {
+		double kd = ph.kn * (double)T.md2[i0];
+		double m2 = fma(kd, Pm.two_rmax + kd, (double)T.mb2[i0]);
+		if (ph.C0 < -m2) { lv = 2; marg = m2; }
+	}
+	const int L = (lv == 0) ? 1 : ((lv == 1) ? PC_L1 : PC_L2);
+	const int i1 = i0 + L;
 	double z1 = T.z[i1], zh1 = T.zh[i1], c2 = T.cap2[i1];
 	double qx = fma(-ph.kx, zh1, fma(ph.sx, z1, ph.ox));
 	double qy = fma(-ph.ky, zh1, fma(ph.sy, z1, ph.oy));
 	double C1 = fma(qx, qx, fma(qy, qy, -c2));
-	int ok = (ph.C0 < -Pm.adj) & (C1 < -Pm.adj);
+	int ok = (ph.C0 < -marg) & (C1 < -marg);
 	if (ph.bnd) {
-		/* boundary capillary (or mono-capillary): the hexagon tests of the visit are not implied, do them:
+		/* boundary capillary (or mono-capillary; always level 0): the hexagon tests of the visit are not implied, do them:
 		 * axis at both nodes (src/polycap-capil.c:1263) and the ray at z_i (:1296-1308) */
-		int i0 = ph.i;
 		double z0 = T.z[i0], zh0 = T.zh[i0], h0 = T.hexd[i0], h1 = T.hexd[i1];
 		double px = fma(ph.sx, z0, ph.ox), py = fma(ph.sy, z0, ph.oy);
 		ok &= !pc_outside_hexd(h0, ph.kx*zh0, ph.ky*zh0);
 		ok &= !pc_outside_hexd(h1, ph.kx*zh1, ph.ky*zh1);
 		ok &= !pc_outside_hexd(h0, px, py);
 	}
-	if (ok) { ph.C0 = C1; ph.i = i1; }
-	return ok;
+	if (ok) { ph.C0 = C1; ph.i = i1; return 1; }
+	if (lv > 0) { ph.lv = lv - 1; return 1; }     /* far node not certified: shorter strides for the rest of this flight */
+	return 0;
 }
 
 /* First segment of a trace call: the last interaction point P lies inside [z_i, z_i+1] and the reference only

@@ -27,7 +27,7 @@
 
 #define PC_BLOCK 512            /* maximum workgroup size the trace kernel is compiled for */
 #define PC_WAVE 64
-#define PC_MAX_PITCH 2560      /* largest profile kept in static LDS: 6 tables x 2560 x 8 B = 120 KB */
+#define PC_MAX_PITCH 2048      /* largest profile kept in static LDS: (6 x 8 + 4 x 4) B x 2048 = 128 KB */
 #define PC_CHUNK 128           /* slots a wave takes from the global counter at a time */
 #define PC_FIX_SCALE 4611686018427387904.0 /* 2^62 */
 #ifndef PC_MIN_WAVES
@@ -54,6 +54,7 @@ struct pc_totals {             /* device-resident totals of one run */
 
 struct pc_kargs {
 	const double *g_z, *g_cap, *g_zh, *g_cap2, *g_hexd, *g_idz, *g_ext;
+	const float *g_mb1, *g_md1, *g_mb2, *g_md2;
 	const pc_energy_const *ec;
 	pc_params pm;
 	unsigned long long seed;
@@ -108,6 +109,7 @@ pc_trace_kernel(pc_kargs a)
 	constexpr bool EXPLICIT = (MODE == PC_MODE_EXPLICIT);
 	/* static LDS with a compile-time pitch: table reads become ds_read with immediate offsets */
 	__shared__ double lds[6*PITCH];
+	__shared__ float ldsf[4*PITCH];
 	const int npts = a.pm.nmax + 1;
 	double *l_z = lds, *l_cap = lds + PITCH, *l_zh = lds + 2*PITCH, *l_cap2 = lds + 3*PITCH, *l_hexd = lds + 4*PITCH, *l_idz = lds + 5*PITCH;
 	for (int k = threadIdx.x; k < npts; k += blockDim.x) {
@@ -117,10 +119,12 @@ pc_trace_kernel(pc_kargs a)
 		l_cap2[k] = a.g_cap2[k];
 		l_hexd[k] = a.g_hexd[k];
 		l_idz[k] = a.g_idz[k];
+		ldsf[k] = a.g_mb1[k]; ldsf[PITCH + k] = a.g_md1[k]; ldsf[2*PITCH + k] = a.g_mb2[k]; ldsf[3*PITCH + k] = a.g_md2[k];
 	}
 	__syncthreads();
 	pc_tables T;
 	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.hexd = l_hexd; T.idz = l_idz; T.ext = a.g_ext;
+	T.mb1 = ldsf; T.md1 = ldsf + PITCH; T.mb2 = ldsf + 2*PITCH; T.md2 = ldsf + 3*PITCH;
 	const long long rec = PC_N_FIELDS + (long long)a.pm.n_energies;   /* doubles per image record */
 	const pc_params &Pm = a.pm;
 	const int ne = (NE > 0) ? NE : Pm.n_energies;
@@ -389,9 +393,10 @@ struct pc_hip_ctx {
 	pc_host_tables host;
 	double *d_tables = nullptr;            /* z, cap, zh, cap2, hexd, idz, ext: 7 x npts */
 	pc_energy_const *d_ec = nullptr;
+	float *d_ftables = nullptr;            /* mb1, md1, mb2, md2: 4 x npts */
 	/* options */
 	int literal = 0;
-	int event_threshold = 24;      /* tuned on MI355X, xos1 10 keV: scripts/ab_bench.sh */
+	int event_threshold = 16;      /* tuned on MI355X, xos1 10 keV: scripts/ab_bench.sh */
 	int new_threshold = 4;
 	int march_burst = 16;
 	int blocks_per_cu = 2;
@@ -418,6 +423,7 @@ static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
 	a.g_z = ctx->d_tables; a.g_cap = ctx->d_tables + npts; a.g_zh = ctx->d_tables + 2*npts;
 	a.g_cap2 = ctx->d_tables + 3*npts; a.g_hexd = ctx->d_tables + 4*npts; a.g_idz = ctx->d_tables + 5*npts;
 	a.g_ext = ctx->d_tables + 6*npts;
+	a.g_mb1 = ctx->d_ftables; a.g_md1 = ctx->d_ftables + npts; a.g_mb2 = ctx->d_ftables + 2*npts; a.g_md2 = ctx->d_ftables + 3*npts;
 	a.ec = ctx->d_ec;
 	a.pm = ctx->host.pm;
 	a.pm.literal = ctx->literal;
@@ -489,6 +495,7 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	if (ctx->d_tables) (void)hipFree(ctx->d_tables);
 	if (ctx->d_ec) (void)hipFree(ctx->d_ec);
+	if (ctx->d_ftables) (void)hipFree(ctx->d_ftables);
 	if (ctx->d_totals) (void)hipFree(ctx->d_totals);
 	if (ctx->d_img) (void)hipFree(ctx->d_img);
 	if (ctx->d_stage) (void)hipFree(ctx->d_stage);
@@ -512,7 +519,7 @@ int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ou
 	int rc = pc_build_tables(problem, ctx->host, err);
 	if (rc) { delete ctx; return pc_fail(rc, "pc_hip_ctx_create: " + err); }
 	const size_t npts = (size_t)ctx->host.pm.nmax + 1;
-	if (npts > PC_MAX_PITCH) { delete ctx; return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_ctx_create: profile too long for the LDS tables (nmax <= 2559)"); }
+	if (npts > PC_MAX_PITCH) { delete ctx; return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_ctx_create: profile too long for the LDS tables (nmax <= 2047)"); }
 #define PC_CTX_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); pc_hip_ctx_destroy(ctx); return pc_fail(PC_HIP_ERR_RUNTIME, m); } } while (0)
 	PC_CTX_CHECK(hipSetDevice(device));
 	hipDeviceProp_t prop;
@@ -525,6 +532,10 @@ int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ou
 	const std::vector<double> *src[7] = { &ctx->host.z, &ctx->host.cap, &ctx->host.zh, &ctx->host.cap2, &ctx->host.hexd, &ctx->host.idz, &ctx->host.ext };
 	for (int k = 0; k < 7; k++)
 		PC_CTX_CHECK(hipMemcpy(ctx->d_tables + k*npts, src[k]->data(), npts*sizeof(double), hipMemcpyHostToDevice));
+	PC_CTX_CHECK(hipMalloc(&ctx->d_ftables, 4*npts*sizeof(float)));
+	const std::vector<float> *fsrc[4] = { &ctx->host.mb1, &ctx->host.md1, &ctx->host.mb2, &ctx->host.md2 };
+	for (int k = 0; k < 4; k++)
+		PC_CTX_CHECK(hipMemcpy(ctx->d_ftables + k*npts, fsrc[k]->data(), npts*sizeof(float), hipMemcpyHostToDevice));
 	PC_CTX_CHECK(hipMalloc(&ctx->d_ec, ctx->host.ec.size()*sizeof(pc_energy_const)));
 	PC_CTX_CHECK(hipMemcpy(ctx->d_ec, ctx->host.ec.data(), ctx->host.ec.size()*sizeof(pc_energy_const), hipMemcpyHostToDevice));
 	ctx->totals_bytes = sizeof(pc_totals) + 2*ctx->host.ec.size()*sizeof(unsigned long long);

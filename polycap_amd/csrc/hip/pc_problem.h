@@ -28,6 +28,7 @@
 
 struct pc_host_tables {
 	std::vector<double> z, cap, zh, cap2, hexd, idz, ext;
+	std::vector<float> mb1, md1, mb2, md2;   /* block-certificate tables for strides PC_L1, PC_L2 */
 	std::vector<pc_energy_const> ec;
 	pc_params pm;
 };
@@ -86,6 +87,36 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 	}
 	double m = std::fmax(1e-6*capmin*capmin, 1e-10*capmax*extmax);
 	pm.adj = 0.25*dr2max + m;
+	pm.two_rmax = 2.*capmax;
+	/* block certificates: for every start node the chord deviations over the next L segments */
+	for (int lvl = 1; lvl <= 2; lvl++) {
+		const int L = (lvl == 1) ? PC_L1 : PC_L2;
+		std::vector<float> &mb = (lvl == 1) ? t.mb1 : t.mb2;
+		std::vector<float> &md = (lvl == 1) ? t.md1 : t.md2;
+		mb.assign(n, HUGE_VALF);
+		md.assign(n, HUGE_VALF);
+		for (int i = 0; i + L < n; i++) {
+			const double za = p->z[i], zb = p->z[i+L], span = zb - za;
+			double dzh = 0., dr = 0.;
+			for (int j = i + 1; j < i + L; j++) {
+				double u = (p->z[j] - za)/span;
+				double zc = t.zh[i] + (t.zh[i+L] - t.zh[i])*u;
+				double rc = p->cap[i] + (p->cap[i+L] - p->cap[i])*u;
+				dzh = std::fmax(dzh, std::fabs(t.zh[j] - zc));
+				dr = std::fmax(dr, std::fabs(p->cap[j] - rc));
+			}
+			/* 1e-12 relative slack covers the rounding of the chord evaluation itself */
+			dzh = dzh*(1. + 1e-9) + 1e-12*std::fabs(t.zh[i]);
+			dr = dr*(1. + 1e-9) + 1e-12*capmax;
+			double dR = p->cap[i+L] - p->cap[i];
+			double base = 0.25*dR*dR + pm.two_rmax*dr + m;
+			float fb = (float)base, fd = (float)dzh;
+			if ((double)fb < base) fb = std::nextafter(fb, HUGE_VALF);
+			if ((double)fd < dzh) fd = std::nextafter(fd, HUGE_VALF);
+			mb[i] = fb;
+			md[i] = fd;
+		}
+	}
 	pm.bnd_thresh = ratio + 1e-9;
 
 	t.ec.resize(p->n_energies);

@@ -254,9 +254,64 @@ def test_public_c_api_on_gpu(pa, oracle, known):
             assert w is None
         else:
             assert w is not None and w.shape == (1,)
-    src = capi.Source(desc, 2000.0, 0.2065, 0.2065, 0.0, 0.0, 0.0, 0.0, 0.5, np.array([10.0]))
-    eff = src.get_transmission_efficiencies(-1, 20000)
+    # reference tests/source.c:165-278: seven energies, 30000 photons, published curve and per-photon sanity checks
+    t = known["transmission_curve"]
+    src = capi.Source(desc, t["d_source"], t["src_x"], t["src_y"], t["src_sigx"], t["src_sigy"], t["src_shiftx"],
+                      t["src_shifty"], t["hor_pol"], np.array(t["energies"], dtype=np.float64))
+    eff = src.get_transmission_efficiencies(-1, t["n_photons"])
     energies, effs = eff.data
-    assert abs(effs[0] - 0.135) <= 0.0075
+    assert eff.data is eff.data and not effs.flags.writeable          # tests/python.py:230-235, 262-277
+    assert np.all(np.abs(effs - np.array(t["efficiencies"])) <= np.array(t["tolerances"]))
+    assert len(list(eff.start_coords)) == t["n_photons"]
+    w = eff.exit_weights
+    assert w.shape == (t["n_photons"], 7) and w[0, 0] >= 3.5e-4 and np.all((w >= 0) & (w <= 1))
+    assert 0 < eff.n_refl[0] < 200 and eff.d_travel[0] >= 9. and next(iter(eff.exit_coords)).z == 9.
+    assert next(iter(eff.start_direction)) == (0., 0., 1.)
+    with pytest.raises(ValueError):
+        eff.write_hdf5(None)
     photon = src.get_photon(capi.Rng(20000))
     assert abs(photon.start_coords[0]) <= 0.2065
+
+
+def test_full_size_properties_xos1_1e7(pa):
+    """BASELINE config C2 at full size (xos1.inp, 10 keV, 1e7 exit photons): size-independent properties instead of
+    an oracle run -- exact bookkeeping identities, exact partition invariance of the totals, physical sanity, and
+    agreement with the efficiency of an independent 2e5-slot sample within its statistical error."""
+    import os
+    from tests.conftest import EXAMPLE
+    prob = pa.problem_from_inp(os.path.join(EXAMPLE, "xos1.inp"), energies=[10.0])
+    n = 10_000_000
+    with pa.TraceContext(prob) as ctx:
+        full = ctx.transmission(20000, 0, n, keep_images=True)
+        parts = [ctx.transmission(20000, s0, c) for s0, c in ((0, 3_000_001), (3_000_001, 6_999_999))]
+        small = ctx.transmission(4242, 0, 200_000)
+    assert full["i_exit"] == n and full["failed_slots"] == 0
+    assert full["launches"] >= full["i_start"]                       # launches also count photons that missed the optic / errored
+    # checksum of checksums: per-slot weights and reflection counts add up to the exact fixed-point totals
+    w = full["exit_weights"][:, 0]
+    tot = int(full["sumw_fixed"][0, 0]) + (int(full["sumw_fixed"][0, 1]) << 64)
+    assert sum(int(x) for x in np.floor(w * 4611686018427387904.0).astype(np.uint64)) == tot
+    assert int(full["nrefl"].sum()) == full["sum_irefl"]
+    # exact partition invariance at full size
+    assert np.array_equal(full["counters"][:4], parts[0]["counters"][:4] + parts[1]["counters"][:4])
+    lo = sum(int(p["sumw_fixed"][0, 0]) for p in parts)
+    hi = sum(int(p["sumw_fixed"][0, 1]) for p in parts) + (lo >> 64)
+    assert (lo & (2**64 - 1), hi) == (int(full["sumw_fixed"][0, 0]), int(full["sumw_fixed"][0, 1]))
+    # physics: every exit photon sits in the exit window at z = 9 cm with 1e-4 <= weight <= 1, travelled >= 9 cm
+    img = full["images"]
+    names = list(pa.IMG_FIELDS)
+    col = lambda k: img[:, names.index(k)]
+    assert np.all(col("pc_exit_z") == prob.z[-1]) and np.all(col("dtravel") >= prob.z[-1])
+    assert np.all(np.hypot(col("pc_exit_x"), col("pc_exit_y")) <= prob.ext[-1] + 1e-12)
+    assert np.all((w >= 1e-4) & (w <= 1.0))
+    assert np.all(np.hypot(col("src_start_x"), col("src_start_y")) <= 0.2065 * (1 + 1e-12))
+    # simulated open area (iexit+not_trans)/i_start equals the fraction of the entrance covered by capillaries
+    # (reference prints both, src/polycap-source.c:1062): calculated 0.6586 for xos1; statistical error ~1e-4
+    n_sh = round(np.sqrt(12. * prob.n_cap - 3.) / 6. - 0.5)
+    calc = ((n_sh + 0.5) * 6.) ** 2 / 12. * (prob.cap[0] ** 2 * np.pi) / (3. * np.sin(np.pi / 3) * prob.ext[0] ** 2)
+    sim = (full["i_exit"] + full["not_transmitted"]) / full["i_start"]
+    assert abs(sim - calc) < 2e-3
+    # independent seed: efficiencies agree within 5 sigma of the small sample (sigma_rel ~ 1.08/sqrt(N_started), SURVEY 8d)
+    sig = 1.08 / np.sqrt(small["i_start"])
+    assert abs(small["efficiencies"][0] - full["efficiencies"][0]) / full["efficiencies"][0] < 5 * sig
+    assert 35.0 < full["sum_irefl"] / n < 42.0     # reflections per exit photon (SURVEY: 38.3-38.6)

@@ -158,3 +158,17 @@ def test_transmission_partition_invariance(oracle, known, optic):
     b1 = oracle.transmission(optic, src, [10.0], [g["amu"]], [g["scatf"]], 7, 250, 350, n_threads=2, images=True)
     assert np.array_equal(a["images"], np.vstack([b0["images"], b1["images"]]))
     assert np.array_equal(a["counters"], b0["counters"] + b1["counters"])
+
+
+def test_transmission_curve_all_seven_energies(oracle, known, optic):
+    """tests/source.c:216-222, all seven energies: oracle + libpolycap's built-in O/Si optical constants reproduce the
+    reference's published curve (0.424, 0.349, 0.135, 0.050, 0.022, 0.011, 0.006) within the reference's tolerances.
+    This is the only pin the reference offers for optical constants away from 10 keV (statistical, through xraylib)."""
+    import polycap_amd
+    t, g = known["transmission_curve"], known["glass"]
+    E = np.array(t["energies"], dtype=np.float64)
+    amu, scatf, _ = polycap_amd.optical_constants(g["iz"], g["wi_percent"], g["density"], E)
+    src = oracle.make_source(t["d_source"], t["src_x"], t["src_y"], t["src_sigx"], t["src_sigy"],
+                             t["src_shiftx"], t["src_shifty"], t["hor_pol"])
+    r = oracle.transmission(optic, src, E, amu, scatf, 20000, 0, t["n_photons"])
+    assert np.all(np.abs(r["efficiencies"] - np.array(t["efficiencies"])) <= np.array(t["tolerances"]))
