@@ -90,12 +90,13 @@ struct pc_photon {
 	double C0;              /* |p - axis|^2 - cap^2 at node i (certificate chain) */
 	double dtravel;
 	double w[NE > 0 ? NE : 1]; /* NE > 0: one weight per energy in registers */
-	double *wmem;              /* NE == 0: n_energies weights in memory at wmem[e*wstride] */
+	double *wmem;              /* NE == 0: n_energies weights in memory at wmem[e*wstride], valid once wset != 0 */
 	long wstride;
 	int i;                  /* segment [z_i, z_i+1] to be visited next */
 	int irefl;
 	int ntrace;             /* completed polycap_capil_trace calls that returned 1 */
 	int first;              /* 1: segment i is the first of a trace call (last hit lies inside it) */
+	int wset;               /* NE == 0: the in-memory weights have been written (before that every weight is 1) */
 	int lv;                 /* widest block-certificate stride still allowed on this flight: 0 single segments, 1 L1, 2 L2 */
 	double kn;              /* |(kx, ky)| */
 	int bnd;                /* 1: boundary capillary, hexagon tests are done at every node */
@@ -311,12 +312,11 @@ PC_HD int pc_launch_init(const pc_tables &T, const pc_params &Pm, pc_photon<NE> 
 	ph.Px = x; ph.Py = y; ph.Pz = z;
 	ph.dx = dx; ph.dy = dy; ph.dz = dz;
 	ph.ex = ex; ph.ey = ey; ph.ez = ez;
-	ph.irefl = 0; ph.ntrace = 0; ph.dtravel = 0.; ph.rc = 0; ph.C0 = 0.; ph.bnd = 0;
-	{
-		const int ne = (NE > 0) ? NE : Pm.n_energies;
-		for (int e = 0; e < ne; e++) {
-			if (NE > 0) ph.w[e] = 1.; else ph.wmem[e*ph.wstride] = 1.;
-		}
+	ph.irefl = 0; ph.ntrace = 0; ph.dtravel = 0.; ph.rc = 0; ph.C0 = 0.; ph.bnd = 0; ph.wset = 0;
+	/* NE == 0: weights live in memory and are initialised lazily (a photon without reflections has weight 1) */
+	if (NE > 0) {
+#pragma unroll
+		for (int e = 0; e < (NE > 0 ? NE : 1); e++) ph.w[e] = 1.;
 	}
 
 	/* :507-512 */
@@ -586,65 +586,102 @@ PC_HD int pc_segment(const pc_tables &T, const pc_photon<NE> &ph, int i,
  * complex reciprocal + cabs; |n x d| = sin(theta) normalises the s direction.  The reference's new electric
  * vector is |E_k| * f / |(|E| f)| for a common factor f (:546-559), i.e. the component-wise absolute value of
  * the (unit) vector.  Returns 1 keep, 0 absorbed, -1 error. */
+/* energy-independent part of a reflection */
+struct pc_refl_geom {
+	double alfa;   /* cos(theta) = n.d, also the roughness argument (:599) */
+	double st2;    /* sin^2(theta) */
+	double es2;    /* (E . (n x d))^2   : frac_s = es2/sd2 */
+	double ep2;    /* sd2 - es2         : frac_p = ep2/sd2 */
+	double sd2;    /* |n x d|^2 */
+};
+
+/* returns -1 when the reference rejects the geometry (alfa < 0, :599-602), else 1 */
 template <int NE>
-PC_HD int pc_reflect(const pc_params &Pm, const pc_energy_const *EC, pc_photon<NE> &ph,
-                     double nx, double ny, double nz)
+PC_HD int pc_reflect_geom(const pc_photon<NE> &ph, double nx, double ny, double nz, pc_refl_geom &g)
 {
-	double alfa = fma(ph.dx, nx, fma(ph.dy, ny, ph.dz*nz));
-	if (alfa < 0.) return -1;                                   /* :599-602 */
-	double ct = alfa;
-	double st2 = fma(-ct, ct, 1.0);
+	g.alfa = fma(ph.dx, nx, fma(ph.dy, ny, ph.dz*nz));
+	if (g.alfa < 0.) return -1;
+	g.st2 = fma(-g.alfa, g.alfa, 1.0);
 	/* :520-537: s = (n x d)/|n x d|, |n x d|^2 = sin^2(theta); frac_s = (E.s)^2 */
 	double sdx = fma(ny, ph.dz, -ph.dy*nz);
 	double sdy = fma(nz, ph.dx, -ph.dz*nx);
 	double sdz = fma(nx, ph.dy, -ph.dx*ny);
 	double es = fma(ph.ex, sdx, fma(ph.ey, sdy, ph.ez*sdz));
-	double es2 = es*es;                                         /* frac_s = es2/sd2, frac_p = (sd2-es2)/sd2 */
-	double sd2 = fma(sdx, sdx, fma(sdy, sdy, sdz*sdz));
-	double ep2 = sd2 - es2;
+	g.es2 = es*es;
+	g.sd2 = fma(sdx, sdx, fma(sdy, sdy, sdz*sdz));
+	g.ep2 = g.sd2 - g.es2;
+	return 1;
+}
 
+/* one energy of src/polycap-capil.c:625-645: w *= rtot * r_rough.  Returns -1 on the reference's error exits,
+ * else 1 when the new weight is still >= 1e-4, else 0. */
+PC_HD int pc_reflect_energy(const pc_energy_const &ec, const pc_refl_geom &g, double &w)
+{
+	if (ec.valid == 0.) return -1;
+	const double ct = g.alfa;
+	/* tmp = n_inv^2 * sin^2 ; csq = csqrt(1 - tmp)   (:503-505) */
+	double wr = fma(-ec.ninv2_re, g.st2, 1.0);
+	double wi = -ec.ninv2_im*g.st2;
+	/* principal complex square root without cancellation: t = sqrt((|w|+|wr|)/2), u = |wi|/(2t);
+	 * (csr, |csi|) = (t, u) for wr >= 0 and (u, t) for wr < 0; the imaginary part takes the sign of wi */
+	double mag = sqrt(fma(wr, wr, wi*wi));
+	double tt = sqrt(0.5*(mag + fabs(wr)));
+	double uu = (tt > 0.) ? fabs(wi)/(2.*tt) : 0.;
+	double csr = (wr >= 0.) ? tt : uu;
+	double csi = copysign((wr >= 0.) ? uu : tt, wi);
+	/* r_s = (cos - n*csq)/(cos + n*csq)   (:507-510) */
+	double tr = fma(ec.n_re, csr, -ec.n_im*csi);
+	double ti = fma(ec.n_re, csi, ec.n_im*csr);
+	double nr = ct - tr, dr = ct + tr;
+	double Ns = fma(nr, nr, ti*ti), Ds = fma(dr, dr, ti*ti);
+	/* r_p = (csq - n*cos)/(csq + n*cos)   (:512-515) */
+	double ur = ec.n_re*ct, ui = ec.n_im*ct;
+	double pr = csr - ur, pi_ = csi - ui, er = csr + ur, ei = csi + ui;
+	double Np = fma(pr, pr, pi_*pi_), Dp = fma(er, er, ei*ei);
+	/* rtot = R_s frac_s + R_p frac_p = (es2 Ns Dp + ep2 Np Ds) / (sd2 Ds Dp): one division */
+	double rtot = fma(g.es2*Ns, Dp, g.ep2*Np*Ds) / (g.sd2*Ds*Dp);
+	if (rtot < 0. || rtot > 1.) return -1;                      /* :633-637 */
+	double cons1 = ec.rough_c*g.alfa;                           /* (1.01358*E)*alfa*sig_rough, :626 */
+	double r_rough = (ec.rough_c == 0.) ? 1.0 : exp(-1.*cons1*cons1);
+	w = w * rtot * r_rough;
+	return (w >= 1.e-4) ? 1 : 0;
+}
+
+/* whole reflection for one lane: geometry, all energies in order (stopping at the first error like the reference),
+ * new electric vector.  Returns 1 keep, 0 absorbed, -1 error. */
+template <int NE>
+PC_HD int pc_reflect(const pc_params &Pm, const pc_energy_const *EC, pc_photon<NE> &ph,
+                     double nx, double ny, double nz)
+{
+	pc_refl_geom g;
+	if (pc_reflect_geom(ph, nx, ny, nz, g) < 0) return -1;
 	int keep = 0;
 	const int ne = (NE > 0) ? NE : Pm.n_energies;
 	for (int e = 0; e < ne; e++) {
-		const pc_energy_const ec = EC[e];
-		if (ec.valid == 0.) return -1;
-		/* tmp = n_inv^2 * sin^2 ; csq = csqrt(1 - tmp)   (:503-505) */
-		double wr = fma(-ec.ninv2_re, st2, 1.0);
-		double wi = -ec.ninv2_im*st2;
-		/* principal complex square root without cancellation: t = sqrt((|w|+|wr|)/2), u = |wi|/(2t);
-		 * (csr, |csi|) = (t, u) for wr >= 0 and (u, t) for wr < 0; the imaginary part takes the sign of wi */
-		double mag = sqrt(fma(wr, wr, wi*wi));
-		double tt = sqrt(0.5*(mag + fabs(wr)));
-		double uu = (tt > 0.) ? fabs(wi)/(2.*tt) : 0.;
-		double csr = (wr >= 0.) ? tt : uu;
-		double csi = copysign((wr >= 0.) ? uu : tt, wi);
-		/* r_s = (cos - n*csq)/(cos + n*csq)   (:507-510) */
-		double tr = fma(ec.n_re, csr, -ec.n_im*csi);
-		double ti = fma(ec.n_re, csi, ec.n_im*csr);
-		double nr = ct - tr, dr = ct + tr;
-		double Ns = fma(nr, nr, ti*ti), Ds = fma(dr, dr, ti*ti);
-		/* r_p = (csq - n*cos)/(csq + n*cos)   (:512-515) */
-		double ur = ec.n_re*ct, ui = ec.n_im*ct;
-		double pr = csr - ur, pi_ = csi - ui, er = csr + ur, ei = csi + ui;
-		double Np = fma(pr, pr, pi_*pi_), Dp = fma(er, er, ei*ei);
-		/* rtot = R_s frac_s + R_p frac_p = (es2 Ns Dp + ep2 Np Ds) / (sd2 Ds Dp): one division */
-		double rtot = fma(es2*Ns, Dp, ep2*Np*Ds) / (sd2*Ds*Dp);
-		if (rtot < 0. || rtot > 1.) return -1;                  /* :633-637 */
-		double cons1 = ec.rough_c*alfa;                         /* (1.01358*E)*alfa*sig_rough, :626 */
-		double r_rough = (ec.rough_c == 0.) ? 1.0 : exp(-1.*cons1*cons1);
-		double we = (NE > 0) ? ph.w[NE > 0 ? e : 0] : ph.wmem[e*ph.wstride];
-		we = we * rtot * r_rough;
+		double we = (NE > 0) ? ph.w[NE > 0 ? e : 0] : (ph.wset ? ph.wmem[e*ph.wstride] : 1.0);
+		int r = pc_reflect_energy(EC[e], g, we);
+		if (r < 0) return -1;
 		if (NE > 0) ph.w[NE > 0 ? e : 0] = we; else ph.wmem[e*ph.wstride] = we;
-		if (we >= 1.e-4) keep = 1;
+		keep |= r;
 	}
+	ph.wset = 1;
 	ph.ex = fabs(ph.ex); ph.ey = fabs(ph.ey); ph.ez = fabs(ph.ez);
 	return keep;
 }
 
 /* ------------------------------------------------------------------ EVENT: one literal segment visit
- * src/polycap-capil.c:1246-1358 for segment ph.i, including what follows a hit.  Returns the next state. */
+ * src/polycap-capil.c:1246-1358 for segment ph.i, split so that kernels can run the per-energy loop of the
+ * reflection cooperatively: pc_event_pre() does everything up to the reflection and returns PC_ST_REFLECT with the
+ * hit data when one is due; pc_event_post() applies its outcome. */
+#define PC_ST_REFLECT 6
+
+struct pc_hit {
+	double nx, ny, nz, cosalfa;
+	int ix;
+};
+
 template <int NE>
-PC_HD int pc_event(const pc_tables &T, const pc_params &Pm, const pc_energy_const *EC, pc_photon<NE> &ph)
+PC_HD int pc_event_pre(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph, pc_hit &h)
 {
 	const int i = ph.i;
 	const int nmax = Pm.nmax;
@@ -657,10 +694,11 @@ PC_HD int pc_event(const pc_tables &T, const pc_params &Pm, const pc_energy_cons
 			ph.rc = -1; return PC_ST_DONE;
 		}
 	}
-	double p0x, p0y, hx, hy, hz, nx, ny, nz;
-	int iesc = pc_segment(T, ph, i, p0x, p0y, hx, hy, hz, nx, ny, nz);
-	double cosalfa = fma(nx, ph.dx, fma(ny, ph.dy, nz*ph.dz));
+	double p0x, p0y, hx, hy, hz;
+	int iesc = pc_segment(T, ph, i, p0x, p0y, hx, hy, hz, h.nx, h.ny, h.nz);
+	double cosalfa = fma(h.nx, ph.dx, fma(h.ny, ph.dy, h.nz*ph.dz));
 	if (cosalfa < 0.) iesc = -5;                                /* acos(cosalfa) > pi/2, :1270-1273 */
+	h.cosalfa = cosalfa;
 
 	if (iesc != 1) {
 		/* :1296-1308 the ray at z_i must still be inside the optic (trace -3 -> launch -1) */
@@ -687,6 +725,7 @@ PC_HD int pc_event(const pc_tables &T, const pc_params &Pm, const pc_energy_cons
 	if (fabs(cosalfa) > 1.0) { ph.rc = -1; return PC_ST_DONE; } /* :1325-1327 */
 	/* :1330-1333 rescan: last node index < nmax with z <= hit z (z strictly increasing, z_i <= hz <= z_i+1) */
 	int ix = (hz >= T.z[i+1] && i + 1 < nmax) ? i + 1 : i;
+	h.ix = ix;
 	/* :1334-1343 */
 	if (ph.bnd) {
 		double cur_ext = ((T.ext[ix+1] - T.ext[ix])/(T.z[ix+1] - T.z[ix])) * (hz - T.z[ix]) + T.ext[ix];
@@ -696,20 +735,35 @@ PC_HD int pc_event(const pc_tables &T, const pc_params &Pm, const pc_energy_cons
 			if (pc_outside_hex(cur_ext, hx, hy)) { ph.rc = -1; return PC_ST_DONE; }
 		}
 	}
-	/* :1345-1355 */
-	int r = pc_reflect(Pm, EC, ph, nx, ny, nz);
+	return PC_ST_REFLECT;
+}
+
+/* r = outcome of the reflection (1 keep, 0 absorbed, -1 error): :1345-1355 and the launch loop bound */
+template <int NE>
+PC_HD int pc_event_post(const pc_params &Pm, pc_photon<NE> &ph, const pc_hit &h, int r)
+{
 	if (r == 0) { ph.rc = 0; return PC_ST_DONE; }
 	if (r != 1) { ph.rc = -1; return PC_ST_DONE; }
 	/* mirror reflection of a unit vector about a unit normal stays unit: the reference's re-normalisation is a no-op up to rounding */
-	ph.dx = fma(-2.0*cosalfa, nx, ph.dx);
-	ph.dy = fma(-2.0*cosalfa, ny, ph.dy);
-	ph.dz = fma(-2.0*cosalfa, nz, ph.dz);
+	ph.dx = fma(-2.0*h.cosalfa, h.nx, ph.dx);
+	ph.dy = fma(-2.0*h.cosalfa, h.ny, ph.dy);
+	ph.dz = fma(-2.0*h.cosalfa, h.nz, ph.dz);
 	ph.irefl++;
 	ph.ntrace++;
-	if (ph.ntrace > nmax) { ph.rc = 1; return PC_ST_DONE; }     /* src/polycap-photon.c:912-919: at most nmax+1 calls */
-	ph.i = ix;
+	if (ph.ntrace > Pm.nmax) { ph.rc = 1; return PC_ST_DONE; } /* src/polycap-photon.c:912-919: at most nmax+1 calls */
+	ph.i = h.ix;
 	pc_trace_begin(ph);
 	return PC_ST_MARCH;
+}
+
+template <int NE>
+PC_HD int pc_event(const pc_tables &T, const pc_params &Pm, const pc_energy_const *EC, pc_photon<NE> &ph)
+{
+	pc_hit h;
+	int st = pc_event_pre(T, Pm, ph, h);
+	if (st != PC_ST_REFLECT) return st;
+	int r = pc_reflect(Pm, EC, ph, h.nx, h.ny, h.nz);
+	return pc_event_post(Pm, ph, h, r);
 }
 
 /* MARCH step wrapper: returns the next state (MARCH to keep going, EVENT, or DONE at the end of the optic) */

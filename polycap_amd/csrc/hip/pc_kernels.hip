@@ -28,6 +28,7 @@
 #define PC_BLOCK 512            /* maximum workgroup size the trace kernel is compiled for */
 #define PC_WAVE 64
 #define PC_MAX_PITCH 2048      /* largest profile kept in static LDS: (6 x 8 + 4 x 4) B x 2048 = 128 KB */
+#define PC_KE 5                /* energies per lane whose weights are in flight together in a cooperative sweep */
 #define PC_CHUNK 128           /* slots a wave takes from the global counter at a time */
 #define PC_FIX_SCALE 4611686018427387904.0 /* 2^62 */
 #ifndef PC_MIN_WAVES
@@ -56,6 +57,7 @@ struct pc_kargs {
 	const double *g_z, *g_cap, *g_zh, *g_cap2, *g_hexd, *g_idz, *g_ext;
 	const float *g_mb1, *g_md1, *g_mb2, *g_md2;
 	const pc_energy_const *ec;
+	const double *ec_soa;         /* the same constants field-major [6][n_energies]: coalesced loads in the cooperative sweeps */
 	pc_params pm;
 	unsigned long long seed;
 	long long slot0, n_slots;
@@ -67,7 +69,7 @@ struct pc_kargs {
 	unsigned long long *sumw;     /* 2*n_energies */
 	double *img;                  /* [n_slots][17 + n_energies] records, or NULL */
 	int new_threshold;
-	int pad1;
+	int lds_acc;                  /* NE == 0: accumulate weight sums in LDS (2*n_energies u64 of dynamic LDS) */
 	double *wscratch;             /* NE==0: n_energies * total_threads */
 	long long total_threads;
 	/* explicit-photon mode */
@@ -110,6 +112,8 @@ pc_trace_kernel(pc_kargs a)
 	/* static LDS with a compile-time pitch: table reads become ds_read with immediate offsets */
 	__shared__ double lds[6*PITCH];
 	__shared__ float ldsf[4*PITCH];
+	/* NE == 0: per-workgroup exact weight sums, (lo, hi) per energy, when they fit (a.lds_acc); else global atomics */
+	extern __shared__ unsigned long long l_acc[];
 	const int npts = a.pm.nmax + 1;
 	double *l_z = lds, *l_cap = lds + PITCH, *l_zh = lds + 2*PITCH, *l_cap2 = lds + 3*PITCH, *l_hexd = lds + 4*PITCH, *l_idz = lds + 5*PITCH;
 	for (int k = threadIdx.x; k < npts; k += blockDim.x) {
@@ -121,6 +125,8 @@ pc_trace_kernel(pc_kargs a)
 		l_idz[k] = a.g_idz[k];
 		ldsf[k] = a.g_mb1[k]; ldsf[PITCH + k] = a.g_md1[k]; ldsf[2*PITCH + k] = a.g_mb2[k]; ldsf[3*PITCH + k] = a.g_md2[k];
 	}
+	if (NE == 0 && a.lds_acc)
+		for (int k = threadIdx.x; k < 2*a.pm.n_energies; k += blockDim.x) l_acc[k] = 0ull;
 	__syncthreads();
 	pc_tables T;
 	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.hexd = l_hexd; T.idz = l_idz; T.ext = a.g_ext;
@@ -132,8 +138,11 @@ pc_trace_kernel(pc_kargs a)
 	const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 
 	pc_photon<NE> ph;
-	ph.wmem = (NE > 0) ? nullptr : (a.wscratch + gtid);
-	ph.wstride = (long)a.total_threads;
+	/* NE == 0: the lane's n_energies weights are contiguous, so the wave can sweep one photon's weights with 64
+	 * lanes over energies (coalesced) in the cooperative loops below */
+	ph.wmem = (NE > 0) ? nullptr : (a.wscratch + gtid*(long long)a.pm.n_energies);
+	ph.wstride = 1;
+	ph.wset = 0;
 	ph.rc = 0;
 
 	int state = LS_NEED_SLOT;
@@ -184,18 +193,82 @@ pc_trace_kernel(pc_kargs a)
 		} else if (nE > 0 && !(do_new && nN > nE)) {
 			/* ---------------- EVENT: full quadratic of one segment (+ wall hit, Fresnel reflection) */
 			st_event += 1; st_event_l += (unsigned)nE;
-			if (state == LS_EVENT)
-				state = pc_event(T, Pm, a.ec, ph);
+			if (NE > 0) {
+				if (state == LS_EVENT)
+					state = pc_event(T, Pm, a.ec, ph);
+			} else {
+				/* many energies: geometry per lane, then the wave sweeps each pending photon's weights with all 64
+				 * lanes over energies (coalesced, full lane utilisation whatever the number of pending photons) */
+				pc_hit h;
+				pc_refl_geom g;
+				int pend = 0, res = 0;
+				h.nx = h.ny = h.nz = h.cosalfa = 0.; h.ix = 0;
+				g.alfa = g.st2 = g.es2 = g.ep2 = g.sd2 = 0.;
+				if (state == LS_EVENT) {
+					int st = pc_event_pre(T, Pm, ph, h);
+					if (st == PC_ST_REFLECT) {
+						if (pc_reflect_geom(ph, h.nx, h.ny, h.nz, g) < 0) { pend = 2; res = -1; }
+						else pend = 1;
+					} else {
+						state = st;
+					}
+				}
+				unsigned long long mP = __ballot(pend == 1);
+				const long long wave_gtid0 = gtid - lane;
+				while (mP) {
+					const int p = __ffsll((long long)mP) - 1;
+					mP &= mP - 1ull;
+					pc_refl_geom gp;
+					gp.alfa = __shfl(g.alfa, p, PC_WAVE); gp.st2 = __shfl(g.st2, p, PC_WAVE);
+					gp.es2 = __shfl(g.es2, p, PC_WAVE); gp.ep2 = __shfl(g.ep2, p, PC_WAVE); gp.sd2 = __shfl(g.sd2, p, PC_WAVE);
+					const int wset_p = __shfl(ph.wset, p, PC_WAVE);
+					double *wp = a.wscratch + (wave_gtid0 + p)*(long long)ne;
+					int bad = 0, keep = 0;
+					for (int e0 = 0; e0 < ne; e0 += PC_WAVE*PC_KE) {
+						/* all loads of this sweep are issued before the first Fresnel evaluation */
+						double wv[PC_KE];
+#pragma unroll
+						for (int k = 0; k < PC_KE; k++) {
+							const int e = e0 + k*PC_WAVE + lane;
+							wv[k] = (wset_p && e < ne) ? wp[e] : 1.0;
+						}
+#pragma unroll
+						for (int k = 0; k < PC_KE; k++) {
+							const int e = e0 + k*PC_WAVE + lane;
+							if (e < ne) {
+								pc_energy_const ec;
+								ec.n_re = a.ec_soa[e]; ec.n_im = a.ec_soa[ne + e];
+								ec.ninv2_re = a.ec_soa[2*ne + e]; ec.ninv2_im = a.ec_soa[3*ne + e];
+								ec.rough_c = a.ec_soa[4*ne + e]; ec.valid = a.ec_soa[5*ne + e];
+								int r = pc_reflect_energy(ec, gp, wv[k]);
+								wp[e] = wv[k];
+								bad |= (r < 0);
+								keep |= (r > 0);
+							}
+						}
+					}
+					const int anybad = __any(bad), anykeep = __any(keep);
+					if (lane == p) res = anybad ? -1 : (anykeep ? 1 : 0);
+				}
+				if (pend) {
+					if (pend == 1) { ph.wset = 1; ph.ex = fabs(ph.ex); ph.ey = fabs(ph.ey); ph.ez = fabs(ph.ez); }
+					state = pc_event_post(Pm, ph, h, res);
+				}
+			}
 		} else if (nN > 0 && do_new) {
 			st_new += 1; st_new_l += (unsigned)nN;
 			/* ---------------- NEW: finalise finished photons, hand out slots, sample + entrance tests */
+			int coop = 0;                 /* NE == 0: what the cooperative weight sweep has to do for this lane's photon */
+			const long long done_slot = slot;
 			if (state == LS_DONE) {
 				const int rc = ph.rc;
 				if (EXPLICIT) {
 					const long long j = slot;
 					a.out_rc[j] = rc;
-					for (int e = 0; e < ne; e++)
-						a.out_weights[j*ne + e] = (NE > 0) ? ph.w[NE > 0 ? e : 0] : ph.wmem[e*ph.wstride];
+					if (NE > 0)
+						for (int e = 0; e < ne; e++) a.out_weights[j*ne + e] = ph.w[NE > 0 ? e : 0];
+					else
+						coop = 1;    /* weights are copied by the cooperative sweep below */
 					a.out_exit_coords[3*j] = ph.Px; a.out_exit_coords[3*j+1] = ph.Py; a.out_exit_coords[3*j+2] = ph.Pz;
 					a.out_exit_dir[3*j] = ph.dx; a.out_exit_dir[3*j+1] = ph.dy; a.out_exit_dir[3*j+2] = ph.dz;
 					a.out_exit_elecv[3*j] = ph.ex; a.out_exit_elecv[3*j+1] = ph.ey; a.out_exit_elecv[3*j+2] = ph.ez;
@@ -211,17 +284,17 @@ pc_trace_kernel(pc_kargs a)
 					if (ok) {
 						n_exit++;
 						s_irefl += (unsigned long long)ph.irefl;
-						for (int e = 0; e < ne; e++) {
-							double w = (NE > 0) ? ph.w[NE > 0 ? e : 0] : ph.wmem[e*ph.wstride];
-							unsigned long long f = (unsigned long long)(w * PC_FIX_SCALE);
-							if (NE > 0) {
+						if (NE > 0) {
+							for (int e = 0; e < ne; e++) {
+								double w = ph.w[NE > 0 ? e : 0];
+								unsigned long long f = (unsigned long long)(w * PC_FIX_SCALE);
 								unsigned long long old = acc_lo[NE > 0 ? e : 0];
 								acc_lo[NE > 0 ? e : 0] = old + f;
 								acc_hi[NE > 0 ? e : 0] += (old + f < old) ? 1ull : 0ull;
-							} else {
-								pc_atomic_add128(a.sumw + 2*e, f, 0ull);
+								if (a.keep_images) a.img[slot*rec + PC_F_WEIGHTS + e] = w;
 							}
-							if (a.keep_images) a.img[slot*rec + PC_F_WEIGHTS + e] = w;
+						} else {
+							coop = 1;    /* sums and image weights are handled by the cooperative sweep below */
 						}
 						if (a.keep_images) {
 							/* src/polycap-source.c:900-923 */
@@ -242,11 +315,43 @@ pc_trace_kernel(pc_kargs a)
 						attempt++;
 						if (attempt >= a.max_attempts) {
 							n_failed++;
-							if (a.keep_images)
-								for (int e = 0; e < ne; e++) a.img[slot*rec + PC_F_WEIGHTS + e] = 0.;
+							if (a.keep_images) {
+								if (NE > 0) for (int e = 0; e < ne; e++) a.img[slot*rec + PC_F_WEIGHTS + e] = 0.;
+								else coop = 2;   /* zero weights */
+							}
 							state = LS_NEED_SLOT;
 						} else {
 							state = LS_START;
+						}
+					}
+				}
+			}
+			if (NE == 0) {
+				/* cooperative sweep over the weights of the photons finalised above: 64 lanes over energies */
+				unsigned long long mC = __ballot(coop != 0);
+				const long long wave_gtid0 = gtid - lane;
+				while (mC) {
+					const int p = __ffsll((long long)mC) - 1;
+					mC &= mC - 1ull;
+					const int what = __shfl(coop, p, PC_WAVE);
+					const int wset_p = __shfl(ph.wset, p, PC_WAVE);
+					const long long slot_p = __shfl(done_slot, p, PC_WAVE);
+					const double *wp = a.wscratch + (wave_gtid0 + p)*(long long)ne;
+					for (int e = lane; e < ne; e += PC_WAVE) {
+						double w = (what == 2) ? 0. : (wset_p ? wp[e] : 1.0);
+						if (EXPLICIT) {
+							a.out_weights[slot_p*ne + e] = w;
+						} else {
+							if (what == 1) {
+								unsigned long long f = (unsigned long long)(w * PC_FIX_SCALE);
+								if (a.lds_acc) {
+									unsigned long long old = atomicAdd(&l_acc[2*e], f);
+									if (old + f < old) atomicAdd(&l_acc[2*e + 1], 1ull);
+								} else {
+									pc_atomic_add128(a.sumw + 2*e, f, 0ull);
+								}
+							}
+							if (a.keep_images) a.img[slot_p*rec + PC_F_WEIGHTS + e] = w;
 						}
 					}
 				}
@@ -312,6 +417,11 @@ pc_trace_kernel(pc_kargs a)
 		}
 	}
 
+	if (NE == 0 && !EXPLICIT && a.lds_acc) {
+		__syncthreads();          /* every wave of the workgroup has finished its photons */
+		for (int e = threadIdx.x; e < a.pm.n_energies; e += blockDim.x)
+			if (l_acc[2*e] | l_acc[2*e + 1]) pc_atomic_add128(a.sumw + 2*e, l_acc[2*e], l_acc[2*e + 1]);
+	}
 	if (!EXPLICIT) {
 		/* one set of atomics per wave */
 		unsigned long long v0 = pc_wave_sum_u64(n_exit), v1 = pc_wave_sum_u64(n_not_entered), v2 = pc_wave_sum_u64(n_not_trans);
@@ -393,6 +503,7 @@ struct pc_hip_ctx {
 	pc_host_tables host;
 	double *d_tables = nullptr;            /* z, cap, zh, cap2, hexd, idz, ext: 7 x npts */
 	pc_energy_const *d_ec = nullptr;
+	double *d_ec_soa = nullptr;
 	float *d_ftables = nullptr;            /* mb1, md1, mb2, md2: 4 x npts */
 	/* options */
 	int literal = 0;
@@ -425,6 +536,7 @@ static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
 	a.g_ext = ctx->d_tables + 6*npts;
 	a.g_mb1 = ctx->d_ftables; a.g_md1 = ctx->d_ftables + npts; a.g_mb2 = ctx->d_ftables + 2*npts; a.g_md2 = ctx->d_ftables + 3*npts;
 	a.ec = ctx->d_ec;
+	a.ec_soa = ctx->d_ec_soa;
 	a.pm = ctx->host.pm;
 	a.pm.literal = ctx->literal;
 	a.event_threshold = ctx->event_threshold;
@@ -438,10 +550,11 @@ template <int NE, int MODE>
 static int pc_launch_one(pc_hip_ctx *ctx, const pc_kargs &a, int grid)
 {
 	/* table pitch: 1024 entries (48 KB of LDS) covers the reference's generated profiles (nmax = 999) and its example decks */
+	const size_t dyn = (NE == 0 && a.lds_acc) ? 2*(size_t)ctx->host.pm.n_energies*sizeof(unsigned long long) : 0;
 	if (ctx->host.pm.nmax + 1 <= 1024)
-		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, 1024>), dim3(grid), dim3(ctx->block_size), 0, ctx->stream, a);
+		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, 1024>), dim3(grid), dim3(ctx->block_size), dyn, ctx->stream, a);
 	else
-		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, PC_MAX_PITCH>), dim3(grid), dim3(ctx->block_size), 0, ctx->stream, a);
+		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, PC_MAX_PITCH>), dim3(grid), dim3(ctx->block_size), dyn, ctx->stream, a);
 	PC_HIP_CHECK(hipGetLastError());
 	return PC_HIP_OK;
 }
@@ -456,6 +569,7 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 	int grid = (int)(want_blocks < max_blocks ? want_blocks : max_blocks);
 	if (grid < 1) grid = 1;
 	a.total_threads = (long long)grid * block;
+	a.lds_acc = (ne != 1 && 2*(size_t)ne*sizeof(unsigned long long) <= 16384) ? 1 : 0;
 	if (ne != 1) {
 		size_t need = (size_t)ne * (size_t)a.total_threads;
 		if (need > ctx->wscratch_elems) {
@@ -495,6 +609,7 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	if (ctx->d_tables) (void)hipFree(ctx->d_tables);
 	if (ctx->d_ec) (void)hipFree(ctx->d_ec);
+	if (ctx->d_ec_soa) (void)hipFree(ctx->d_ec_soa);
 	if (ctx->d_ftables) (void)hipFree(ctx->d_ftables);
 	if (ctx->d_totals) (void)hipFree(ctx->d_totals);
 	if (ctx->d_img) (void)hipFree(ctx->d_img);
@@ -538,6 +653,17 @@ int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ou
 		PC_CTX_CHECK(hipMemcpy(ctx->d_ftables + k*npts, fsrc[k]->data(), npts*sizeof(float), hipMemcpyHostToDevice));
 	PC_CTX_CHECK(hipMalloc(&ctx->d_ec, ctx->host.ec.size()*sizeof(pc_energy_const)));
 	PC_CTX_CHECK(hipMemcpy(ctx->d_ec, ctx->host.ec.data(), ctx->host.ec.size()*sizeof(pc_energy_const), hipMemcpyHostToDevice));
+	{
+		const size_t ne = ctx->host.ec.size();
+		std::vector<double> soa(6*ne);
+		for (size_t e = 0; e < ne; e++) {
+			const pc_energy_const &c = ctx->host.ec[e];
+			soa[e] = c.n_re; soa[ne + e] = c.n_im; soa[2*ne + e] = c.ninv2_re; soa[3*ne + e] = c.ninv2_im;
+			soa[4*ne + e] = c.rough_c; soa[5*ne + e] = c.valid;
+		}
+		PC_CTX_CHECK(hipMalloc(&ctx->d_ec_soa, soa.size()*sizeof(double)));
+		PC_CTX_CHECK(hipMemcpy(ctx->d_ec_soa, soa.data(), soa.size()*sizeof(double), hipMemcpyHostToDevice));
+	}
 	ctx->totals_bytes = sizeof(pc_totals) + 2*ctx->host.ec.size()*sizeof(unsigned long long);
 	PC_CTX_CHECK(hipMalloc(&ctx->d_totals, ctx->totals_bytes));
 	PC_CTX_CHECK(hipMemset(ctx->d_totals, 0, ctx->totals_bytes));

@@ -75,6 +75,8 @@ int emul_launch_batch(const pc_hip_problem *p, int literal, int use_regs, int64_
 		} else {
 			pc_photon<0> ph; ph.wmem = weights + (size_t)j*ne; ph.wstride = 1;
 			code = run_photon(E, ph, s[0], s[1], s[2], d[0], d[1], d[2], e[0], e[1], e[2], stats);
+			if (!ph.wset)
+				for (size_t k = 0; k < ne; k++) ph.wmem[k] = 1.0;   /* never reflected (or rejected at the entrance) */
 			P[0]=ph.Px; P[1]=ph.Py; P[2]=ph.Pz; D[0]=ph.dx; D[1]=ph.dy; D[2]=ph.dz; Ev[0]=ph.ex; Ev[1]=ph.ey; Ev[2]=ph.ez;
 			ir = ph.irefl; dt = ph.dtravel;
 		}
