@@ -89,17 +89,16 @@ struct pc_photon {
 	double idzd;            /* 1 / dz of the current direction */
 	double C0;              /* |p - axis|^2 - cap^2 at node i (certificate chain) */
 	double dtravel;
+	double kn;              /* |(kx, ky)| */
 	double w[NE > 0 ? NE : 1]; /* NE > 0: one weight per energy in registers */
 	double *wmem;              /* NE == 0: n_energies weights in memory at wmem[e*wstride], valid once wset != 0 */
 	long wstride;
 	int i;                  /* segment [z_i, z_i+1] to be visited next */
 	int irefl;
-	int ntrace;             /* completed polycap_capil_trace calls that returned 1 */
-	int first;              /* 1: segment i is the first of a trace call (last hit lies inside it) */
+	int first;              /* segment i is the first of a trace call (last hit lies inside it) */
+	int bnd;                /* boundary capillary (or mono-capillary): hexagon tests are done at every node */
 	int wset;               /* NE == 0: the in-memory weights have been written (before that every weight is 1) */
 	int lv;                 /* widest block-certificate stride still allowed on this flight: 0 single segments, 1 L1, 2 L2 */
-	double kn;              /* |(kx, ky)| */
-	int bnd;                /* 1: boundary capillary, hexagon tests are done at every node */
 	int rc;                 /* final polycap_photon_launch return code once DONE */
 };
 
@@ -312,7 +311,7 @@ PC_HD int pc_launch_init(const pc_tables &T, const pc_params &Pm, pc_photon<NE> 
 	ph.Px = x; ph.Py = y; ph.Pz = z;
 	ph.dx = dx; ph.dy = dy; ph.dz = dz;
 	ph.ex = ex; ph.ey = ey; ph.ez = ez;
-	ph.irefl = 0; ph.ntrace = 0; ph.dtravel = 0.; ph.rc = 0; ph.C0 = 0.; ph.bnd = 0; ph.wset = 0;
+	ph.irefl = 0; ph.dtravel = 0.; ph.rc = 0; ph.C0 = 0.; ph.bnd = 0; ph.wset = 0;
 	/* NE == 0: weights live in memory and are initialised lazily (a photon without reflections has weight 1) */
 	if (NE > 0) {
 #pragma unroll
@@ -749,8 +748,8 @@ PC_HD int pc_event_post(const pc_params &Pm, pc_photon<NE> &ph, const pc_hit &h,
 	ph.dy = fma(-2.0*h.cosalfa, h.ny, ph.dy);
 	ph.dz = fma(-2.0*h.cosalfa, h.nz, ph.dz);
 	ph.irefl++;
-	ph.ntrace++;
-	if (ph.ntrace > Pm.nmax) { ph.rc = 1; return PC_ST_DONE; } /* src/polycap-photon.c:912-919: at most nmax+1 calls */
+	/* src/polycap-photon.c:912-919: at most nmax+1 trace calls; every call that returns 1 is one reflection */
+	if (ph.irefl > Pm.nmax) { ph.rc = 1; return PC_ST_DONE; }
 	ph.i = h.ix;
 	pc_trace_begin(ph);
 	return PC_ST_MARCH;

@@ -25,7 +25,9 @@
 #include "pc_device.h"
 #include "pc_problem.h"
 
+#ifndef PC_BLOCK
 #define PC_BLOCK 512            /* maximum workgroup size the trace kernel is compiled for */
+#endif
 #define PC_WAVE 64
 #define PC_MAX_PITCH 2048      /* largest profile kept in static LDS: (6 x 8 + 4 x 4) B x 2048 = 128 KB */
 #define PC_KE 5                /* energies per lane whose weights are in flight together in a cooperative sweep */
@@ -148,12 +150,13 @@ pc_trace_kernel(pc_kargs a)
 	int state = LS_NEED_SLOT;
 	long long slot = -1;          /* relative slot index in [0, n_slots) */
 	unsigned int attempt = 0;
-	double c_ae = 1., c_be = 0.;   /* projection constants of the start electric vector (src/polycap-source.c:789-796) */
+	double cosalpha0 = 0.;         /* start_electric_vector . start_direction: projection constants of src/polycap-source.c:789-796 */
 	/* wave-uniform chunk of slots */
 	long long chunk_next = 0, chunk_end = 0;
 
 	/* per-lane totals */
-	unsigned long long n_exit = 0, n_not_entered = 0, n_not_trans = 0, s_irefl = 0, n_failed = 0, n_launch = 0;
+	/* 32 bits per lane are plenty (a lane handles n_slots / total_threads slots); the wave sums are 64-bit */
+	unsigned int n_exit = 0, n_not_entered = 0, n_not_trans = 0, s_irefl = 0, n_failed = 0, n_launch = 0;
 	unsigned long long acc_lo[NE > 0 ? NE : 1], acc_hi[NE > 0 ? NE : 1];
 #pragma unroll
 	for (int e = 0; e < (NE > 0 ? NE : 1); e++) { acc_lo[e] = 0; acc_hi[e] = 0; }
@@ -283,7 +286,7 @@ pc_trace_kernel(pc_kargs a)
 					else if (rc == 1) ok = pc_in_exit_window(Pm, ph);
 					if (ok) {
 						n_exit++;
-						s_irefl += (unsigned long long)ph.irefl;
+						s_irefl += (unsigned int)ph.irefl;
 						if (NE > 0) {
 							for (int e = 0; e < ne; e++) {
 								double w = ph.w[NE > 0 ? e : 0];
@@ -303,6 +306,7 @@ pc_trace_kernel(pc_kargs a)
 							double ex = ph.Px + ph.dx*t, ey = ph.Py + ph.dy*t, ez = ph.Pz + ph.dz*t;
 							r[PC_F_EXITX] = ex; r[PC_F_EXITY] = ey; r[PC_F_EXITZ] = ez;
 							r[PC_F_EDIRX] = ph.dx; r[PC_F_EDIRY] = ph.dy;
+							const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
 							double tx = ph.ex*c_ae + ph.dx*c_be, ty = ph.ey*c_ae + ph.dy*c_be, tz = ph.ez*c_ae + ph.dz*c_be;
 							pc_norm3(tx, ty, tz);
 							r[PC_F_EEVX] = round(tx); r[PC_F_EEVY] = round(ty);
@@ -399,10 +403,9 @@ pc_trace_kernel(pc_kargs a)
 					if (state == LS_MARCH) {
 						/* src/polycap-source.c:779-798: start images of the attempt that is now inside a capillary;
 						 * the slot belongs to this lane, so a later (transmitted) attempt simply overwrites them */
-						double cosalpha = s.ex*s.dx + s.ey*s.dy + s.ez*s.dz;
-						c_ae = 1.0 / sqrt(1.0 - cosalpha*cosalpha);
-						c_be = -1.*c_ae*cosalpha;
+						cosalpha0 = s.ex*s.dx + s.ey*s.dy + s.ez*s.dz;
 						if (a.keep_images) {
+							const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
 							double *r = a.img + slot*rec;
 							r[PC_F_SRCX] = s.srcx; r[PC_F_SRCY] = s.srcy;
 							r[PC_F_STARTX] = s.x; r[PC_F_STARTY] = s.y;
@@ -680,7 +683,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "event_threshold") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "event_threshold must be in [1,64]"); ctx->event_threshold = (int)value; }
 	else if (n == "new_threshold") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "new_threshold must be in [1,64]"); ctx->new_threshold = (int)value; }
 	else if (n == "march_burst") { if (value < 1) return pc_fail(PC_HIP_ERR_INVALID, "march_burst must be >= 1"); ctx->march_burst = (int)value; }
-	else if (n == "block_size") { if (value != 64 && value != 128 && value != 256 && value != 512) return pc_fail(PC_HIP_ERR_INVALID, "block_size must be 64, 128, 256 or 512"); ctx->block_size = (int)value; }
+	else if (n == "block_size") { if (value < 64 || value > PC_BLOCK || (value % 64) != 0) return pc_fail(PC_HIP_ERR_INVALID, "block_size must be a multiple of 64 up to the compiled maximum"); ctx->block_size = (int)value; }
 	else if (n == "blocks_per_cu") { if (value < 1 || value > 8) return pc_fail(PC_HIP_ERR_INVALID, "blocks_per_cu must be in [1,8]"); ctx->blocks_per_cu = (int)value; }
 	else return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_set_option: unknown option " + n);
 	return PC_HIP_OK;

@@ -1,0 +1,36 @@
+"""Condenses gpurun_out/prof_<tag>_* (rocprofv3 csv) into profiles/r01/<tag>_*.{csv,json}."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir = os.path.join(root, "profiles", "r01")
+os.makedirs(out_dir, exist_ok=True)
+ks = glob.glob(os.path.join(root, "gpurun_out", "prof_%s_kt" % tag, "*", "*_kernel_stats.csv"))
+if ks:
+    shutil.copy(ks[0], os.path.join(out_dir, "%s_kernel_stats.csv" % tag))
+summary = {}
+meta = {}
+for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_%s_pmc*" % tag))):
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "pc_trace" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta = dict(kernel=r["Kernel_Name"], VGPR=r["VGPR_Count"], SGPR=r["SGPR_Count"], LDS=r["LDS_Block_Size"],
+                            grid=r["Grid_Size"], workgroup=r["Workgroup_Size"])
+        for k, v in agg.items():
+            summary[k] = sum(v) / len(v)
+summary["meta"] = meta
+summary["note"] = ("averages per dispatch of the trace kernel over bench.py's launches (1e7 exit-photon slots each); "
+                   "FETCH_SIZE / WRITE_SIZE in KB as reported by rocprofv3, collected in separate --pmc passes")
+b = os.path.join(root, "gpurun_out", "bench_%s.json" % tag)
+if os.path.exists(b):
+    shutil.copy(b, os.path.join(out_dir, "%s_bench.json" % tag))
+json.dump(summary, open(os.path.join(out_dir, "%s_pmc_summary.json" % tag), "w"), indent=1)
+print(json.dumps(summary, indent=1))

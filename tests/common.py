@@ -47,3 +47,23 @@ def make_pair(oracle, which="ellip", energies=(PIN_E,), amu=None, scatf=None, si
 def rel(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+
+
+def make_custom(oracle, shape, n_cap, source, energies=(PIN_E,), sig_rough=0.0):
+    """(optic, source, problem, (E, amu, scatf)) for an analytic profile `shape` = (type, length, rext_up, rext_down,
+    rint_up, rint_down, f_up, f_down)."""
+    from polycap_amd import Problem
+    E = np.asarray(energies, dtype=np.float64)
+    if len(E) == 1 and E[0] == PIN_E:
+        amu, scatf = np.array([PIN_AMU]), np.array([PIN_SCATF])
+    else:
+        amu, scatf = synthetic_constants(E)
+    optic = oracle.Optic.from_shape(*shape, sig_rough, n_cap, GLASS["density"])
+    src = oracle.make_source(*source)
+    prob = Problem(optic.z, optic.cap, optic.ext, sig_rough, n_cap, GLASS["density"], E, amu, scatf, *source)
+    return optic, src, prob, (E, amu, scatf)
+
+
+# monocap.inp-like single conical capillary under uniform illumination; 7-capillary optic with a divergent source
+MONO_CASE = dict(shape=(0, 15., 0.012, 0.012, 0.01, 0.0005, 1000., 0.5), n_cap=2, source=(5., 0.0001, 0.0001, -1., 0., 0., 0., 0.))
+SEVEN_CASE = dict(shape=(0, 5., 0.05, 0.04, 0.012, 0.009, 1000., 0.5), n_cap=7, source=(50., 0.05, 0.05, 0.002, 0.002, 0., 0., 0.3))

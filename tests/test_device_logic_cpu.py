@@ -117,3 +117,25 @@ def test_device_logic_vs_oracle_statistics(emul, oracle):
         assert rel(g["weights"][short], o["weights"][short]).max() < 1e-6
         so, sg = o["weights"][o["rc"] == 1, 0].sum(), g["weights"][g["rc"] == 1, 0].sum()
         assert abs(sg - so) / so < 1.0 / np.sqrt(n), (which, so, sg)
+
+
+def test_mono_capillary_and_boundary_capillaries(emul, oracle):
+    """n_shells == 0 (reference mono-capillary branches src/polycap-photon.c:514-537, src/polycap-capil.c:1282-1286) and a
+    one-shell optic where every capillary is a boundary capillary: the per-node hexagon tests run in the march."""
+    from tests.common import make_custom, MONO_CASE, SEVEN_CASE
+    for case in (MONO_CASE, SEVEN_CASE):
+        optic, src, prob, (E, A, S) = make_custom(oracle, **case)
+        n = 20000
+        ph = oracle.sample_photons(optic, src, 5, np.arange(n))
+        assert np.abs(emul.sample(prob, 5, np.arange(n), np.zeros(n)) - ph).max() < 1e-13
+        o = oracle.launch_batch(optic, E, A, S, ph[:, 0:3], ph[:, 3:6], ph[:, 6:9])
+        g = emul.launch_batch(prob, ph[:, 0:3], ph[:, 3:6], ph[:, 6:9])
+        lit = emul.launch_batch(prob, ph[:, 0:3], ph[:, 3:6], ph[:, 6:9], literal=True)
+        for k in ("rc", "weights", "exit_coords", "i_refl", "d_travel"):
+            assert np.array_equal(g[k], lit[k], equal_nan=True)
+        assert len(np.unique(o["rc"])) >= 3
+        # few reflections per photon here: the discrete outcomes agree photon by photon
+        assert np.array_equal(o["rc"], g["rc"]) and np.array_equal(o["i_refl"], g["i_refl"])
+        m = np.isin(o["rc"], (0, 1))
+        assert rel(g["weights"][m], o["weights"][m]).max() < 1e-8
+        assert np.abs(g["exit_coords"][m] - o["exit_coords"][m]).max() < 1e-9

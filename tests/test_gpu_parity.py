@@ -223,6 +223,27 @@ def test_multi_energy_and_roughness(pa, oracle):
     assert np.allclose(t["exit_weights"].sum(axis=0), t["sum_weights"], rtol=1e-12)
 
 
+def test_mono_capillary_and_boundary_capillaries(pa, oracle):
+    """mono-capillary (n_shells == 0) under uniform illumination and a 7-capillary optic (all boundary capillaries)"""
+    from tests.common import make_custom, MONO_CASE, SEVEN_CASE
+    for case in (MONO_CASE, SEVEN_CASE):
+        optic, src, prob, (E, A, S) = make_custom(oracle, **case)
+        n = 20000
+        ph = oracle.sample_photons(optic, src, 5, np.arange(n))
+        o = oracle.launch_batch(optic, E, A, S, ph[:, 0:3], ph[:, 3:6], ph[:, 6:9])
+        with pa.TraceContext(prob) as ctx:
+            assert np.abs(ctx.sample_photons(5, np.arange(n)) - ph).max() < 1e-13
+            g = ctx.launch_photons(ph[:, 0:3], ph[:, 3:6], ph[:, 6:9])
+            t = ctx.transmission(5, 0, 3000, keep_images=True)
+        assert np.array_equal(o["rc"], g["rc"]) and np.array_equal(o["i_refl"], g["i_refl"])
+        m = np.isin(o["rc"], (0, 1))
+        assert rel(g["weights"][m], o["weights"][m]).max() < 1e-8
+        ot = oracle.transmission(optic, src, E, A, S, 5, 0, 3000, images=True)
+        assert t["i_exit"] == 3000 and np.array_equal(t["counters"][:4], ot["counters"])
+        assert np.allclose(t["exit_weights"], ot["exit_weights"], rtol=1e-8, atol=0)
+        assert np.allclose(t["images"][:, :15], ot["images"][:, :15], rtol=0, atol=1e-9)
+
+
 def test_degenerate_source_nan_photons(pa, oracle):
     """cone.inp-style source (src_y = 0): half the photons are NaN and must be absorbed, as in the reference."""
     optic, src, prob, (E, A, S) = make_pair(oracle, "ellip", source=(100., 0.2065, 0., 0., 0., 0., 0., 0.))
