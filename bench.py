@@ -27,6 +27,22 @@ if ROOT not in sys.path:
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this same command, condensed by scripts/summarize_profile.py
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "v5_pmc_summary.json")
+
+
+def measured_traffic(n_local, keep_images):
+    """HBM bytes per launch from the committed PMC summary (same workload only), else None.  FETCH_SIZE and WRITE_SIZE are
+    reported in KB.  The guide's gfx950 correction (FETCH_SIZE x2) is calibrated for 16-B-per-lane streaming reads; this
+    kernel's memory traffic is 8-B-per-lane record writes and scratch reloads, so the raw sum is reported."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            s = json.load(f)
+        if n_local != 10_000_000 or not keep_images:
+            return None
+        return (s["FETCH_SIZE"] + s["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
 BYTES_PER_EXIT_PHOTON = 17 * 8   # 17 image planes of 8 B; + 8 B per energy for exit_coord_weights
 
 
@@ -41,6 +57,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="exit-photon slots of the CPU baseline sample")
     ap.add_argument("--opt", action="append", default=[], help="kernel option name=value (event_threshold, blocks_per_cu, ...)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-process "
+                         "path on a box with fewer GPUs than ranks: ranks then share devices)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -58,17 +77,22 @@ def main():
 
     if polycap_amd.device_count() < 1:
         sys.exit("bench.py: no HIP device (the trace path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % polycap_amd.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if args.backend == "nccl" else None       # gloo reduces host tensors
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     deck = os.path.join(ROOT, "tests", "golden", "example", "xos1.inp")
     prob = polycap_amd.problem_from_inp(deck, energies=[10.0])
     ne = prob.n_energies
     keep_images = not args.no_images
-    ctx = polycap_amd.TraceContext(prob, local_rank)
+    ctx = polycap_amd.TraceContext(prob, dev_index)
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
@@ -85,7 +109,7 @@ def main():
         ms = ctx.wait()
         t = ctx.totals()
         vec = pcd.pack_totals(t["counters"], t["sumw_fixed"])
-        vec = pcd.allreduce_totals(vec, dev)
+        vec = pcd.allreduce_totals(vec, red_dev)
         return ms, vec
 
     for k in range(args.warmup):
@@ -104,7 +128,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
 
@@ -138,7 +162,7 @@ def main():
             "started_per_exit": started / max(1, exited),
             "scheduler": ctx.phase_stats(),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local, keep_images),
                          "kernel": "pc_trace_kernel<1,0>", "kernel_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "fp64-VALU/divergence-bound by construction (SURVEY 8d): 144 B per exit photon"},
