@@ -62,7 +62,23 @@ def build(force=False, verbose=False):
         objs.append(obj)
     if force or _newer(LIB, objs):
         _run(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-lm"], verbose)
+    build_cython(force=force, verbose=verbose)
     return LIB
+
+
+def build_cython(force=False, verbose=False):
+    """The `polycap` Python module (Cython, same surface as the reference's python/polycap.pyx), linked against
+    libpolycap.so with an $ORIGIN-relative rpath; lands in polycap_amd/pyext/ (add that directory to sys.path)."""
+    import sysconfig
+    pyx = os.path.join(HERE, "pyext", "polycap.pyx")
+    cpp = os.path.join(HERE, "pyext", "polycap.cpp")
+    so = os.path.join(HERE, "pyext", "polycap" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    if force or _newer(cpp, [pyx]):
+        _run([sys.executable, "-m", "cython", "-3", "--cplus", pyx, "-o", cpp], verbose)
+    if force or _newer(so, [cpp, LIB]):
+        _run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-w", "-I" + sysconfig.get_paths()["include"], "-I" + INC, cpp,
+              "-L" + LIBDIR, "-lpolycap", "-Wl,-rpath,$ORIGIN/../lib", "-o", so], verbose)
+    return so
 
 
 if __name__ == "__main__":

@@ -30,6 +30,9 @@
 #endif
 #define PC_WAVE 64
 #define PC_MAX_PITCH 2048      /* largest profile kept in static LDS: (6 x 8 + 4 x 4) B x 2048 = 128 KB */
+#ifndef PC_MARCH_UNROLL
+#define PC_MARCH_UNROLL 4      /* march steps between two ballots of the burst loop */
+#endif
 #define PC_KE 5                /* energies per lane whose weights are in flight together in a cooperative sweep */
 #define PC_CHUNK 128           /* slots a wave takes from the global counter at a time */
 #define PC_FIX_SCALE 4611686018427387904.0 /* 2^62 */
@@ -184,11 +187,11 @@ pc_trace_kernel(pc_kargs a)
 					state = pc_march_step(T, Pm, ph);
 				for (int b = 0; b < a.march_burst; b++) {
 #pragma unroll
-					for (int u = 0; u < 4; u++)
+					for (int u = 0; u < PC_MARCH_UNROLL; u++)
 						if (state == LS_MARCH)
 							state = pc_march_step_hot(T, Pm, ph);
 					const int cM = __popcll(__ballot(state == LS_MARCH));
-					st_march += 4; st_march_l += 4*(unsigned)cM;
+					st_march += PC_MARCH_UNROLL; st_march_l += PC_MARCH_UNROLL*(unsigned)cM;
 					if (cM == 0) break;
 					if (cM < a.event_threshold && (cM != nM || do_new || nE > 0)) break;
 				}

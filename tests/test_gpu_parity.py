@@ -258,9 +258,18 @@ def test_degenerate_source_nan_photons(pa, oracle):
     assert nan.sum() > 100 and np.array_equal(o["rc"][nan], g["rc"][nan])
 
 
-def test_public_c_api_on_gpu(pa, oracle, known):
-    """polycap_photon_launch / polycap_source_get_transmission_efficiencies through the reference-shaped C API."""
-    from polycap_amd import capi
+@pytest.mark.parametrize("binding", ["ctypes", "cython"])
+def test_public_c_api_on_gpu(pa, oracle, known, binding):
+    """polycap_photon_launch / polycap_source_get_transmission_efficiencies through the reference-shaped C API,
+    via the ctypes classes and via the compiled Cython module `polycap`."""
+    if binding == "ctypes":
+        from polycap_amd import capi
+    else:
+        import os
+        import sys
+        from tests.conftest import ROOT
+        sys.path.insert(0, os.path.join(ROOT, "polycap_amd", "pyext"))
+        import polycap as capi
     prof = capi.Profile(capi.Profile.ELLIPSOIDAL, 9., 0.2065, 0.0585, 0.00035, 9.9153e-5, 1000., 0.5)
     desc = capi.Description(prof, 0.0, 200000, {"O": 53.0, "Si": 47.0}, 2.23)
     l = known["launch"]

@@ -10,10 +10,24 @@ from tests.conftest import EXAMPLE
 from tests.common import TEST_SHAPE
 
 
-@pytest.fixture(scope="module")
-def capi():
-    from polycap_amd import capi
-    return capi
+@pytest.fixture(scope="module", params=["ctypes", "cython"])
+def capi(request):
+    """The reference-shaped Python API, once through ctypes (polycap_amd.capi) and once through the compiled Cython
+    module `polycap` (polycap_amd/pyext, built by build())."""
+    if request.param == "ctypes":
+        from polycap_amd import capi
+        return capi
+    import os
+    import sys
+    from tests.conftest import ROOT
+    from polycap_amd import _build
+    _build.build_cython()
+    ext = os.path.join(ROOT, "polycap_amd", "pyext")
+    if ext not in sys.path:
+        sys.path.insert(0, ext)
+    import polycap
+    assert polycap.__version__ == "1.2"
+    return polycap
 
 
 def test_profile_shapes_match_oracle(capi, oracle):
