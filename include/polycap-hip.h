@@ -113,6 +113,16 @@ POLYCAP_EXTERN void pc_hip_efficiencies(size_t n_energies, const double *sum_wei
 /* exact fixed-point (lo,hi) pair -> double */
 POLYCAP_EXTERN double pc_hip_fixed_to_double(uint64_t lo, uint64_t hi);
 
+
+/* Host-side helper with no reference counterpart: builds the polycap_transmission_efficiencies result object from
+ * totals and (optional) image planes produced elsewhere -- summed over several GPUs / ranks by the caller -- so the
+ * getters and the HDF5 writer serve a sharded run exactly as a single-device one.  `source` is a polycap_source*
+ * (it must outlive the result, as in the reference); counters as pc_hip_transmission_totals(); planes hold n_exit
+ * entries each (NULL planes read as zeros); the efficiency formula is that of src/polycap-source.c:1066-1076.
+ * Returns a polycap_transmission_efficiencies* or NULL with *error (a polycap_error**) set. */
+POLYCAP_EXTERN void *pc_transmission_efficiencies_from_totals(void *source, int64_t n_exit, const double *sum_weights,
+	const int64_t counters[6], const pc_hip_images *planes, void *error);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libpolycap.so")
 
 HOST_SRCS = ["pc_error.c", "pc_rng.c", "pc_profile.c", "pc_description.c", "pc_optconst.c",
-             "pc_photon.c", "pc_source.c", "pc_transeff.c"]
+             "pc_photon.c", "pc_source.c", "pc_transeff.c", "pc_hdf5.c"]
 HIP_SRCS = ["pc_kernels.hip"]
 HIP_DEPS = ["pc_device.h", "pc_problem.h"]
 

@@ -45,6 +45,26 @@ def dptr(a):
     return a.ctypes.data_as(c_double_p)
 
 
+# column order of the [n, 17] image array of TraceContext.images(): planes of struct pc_hip_images, nrefl as column 15
+IMAGE_PLANES = [("src_start_coords", 2), ("pc_start_coords", 2), ("pc_start_dir", 2), ("pc_start_elecv", 2),
+                ("pc_exit_coords", 3), ("pc_exit_dir", 2), ("pc_exit_elecv", 2)]
+
+
+def images_struct(planes, nrefl, weights):
+    """pc_hip_images over planes [17, n] (row 16 = d_travel; row 15 unused), nrefl [n] int64, weights [n, nE]."""
+    s = ImagesS()
+    k = 0
+    for name, m in IMAGE_PLANES:
+        arr = getattr(s, name)
+        for j in range(m):
+            arr[j] = dptr(planes[k])
+            k += 1
+    s.pc_exit_nrefl = nrefl.ctypes.data_as(c_int64_p)
+    s.pc_exit_dtravel = dptr(planes[16])
+    s.exit_coord_weights = dptr(weights)
+    return s
+
+
 class Problem:
     """Owns the numpy arrays behind a pc_hip_problem."""
 
@@ -110,5 +130,7 @@ def lib():
     L.pc_hip_efficiencies.restype = None
     L.pc_hip_fixed_to_double.argtypes = [C.c_uint64, C.c_uint64]
     L.pc_hip_fixed_to_double.restype = C.c_double
+    L.pc_transmission_efficiencies_from_totals.argtypes = [C.c_void_p, C.c_int64, c_double_p, c_int64_p, P(ImagesS), C.c_void_p]
+    L.pc_transmission_efficiencies_from_totals.restype = C.c_void_p
     _LIB = L
     return L

@@ -415,6 +415,35 @@ class TransmissionEfficiencies:
     def exit_weights(self):
         return self._exit()[4]
 
+    @classmethod
+    def from_totals(cls, source, sum_weights, counters, images=None, exit_weights=None):
+        """Result object from totals (and optionally the [n_exit, 17] image array + [n_exit, nE] weights of
+        TraceContext.images()) produced elsewhere, e.g. by polycap_amd.distributed.run_sharded over several GPUs:
+        the getters and write_hdf5 then serve the sharded run as they do a single-device one (no reference counterpart)."""
+        from . import _cabi
+        sw = np.ascontiguousarray(sum_weights, dtype=np.float64)
+        cnt = np.zeros(6, dtype=np.int64)
+        cc = np.asarray(counters, dtype=np.int64).ravel()
+        cnt[:min(6, cc.size)] = cc[:6]
+        n = int(cnt[0])
+        sp = None
+        if images is not None:
+            img = np.asarray(images, dtype=np.float64)
+            if img.shape != (n, 17):
+                raise ValueError("images must have shape (counters[0], 17)")
+            planes = np.ascontiguousarray(img.T)
+            nrefl = np.ascontiguousarray(np.rint(planes[15]).astype(np.int64))
+            w = np.zeros((n, sw.size)) if exit_weights is None else np.ascontiguousarray(exit_weights, dtype=np.float64)
+            if w.shape != (n, sw.size):
+                raise ValueError("exit_weights must have shape (counters[0], n_energies)")
+            sp = C.byref(_cabi.images_struct(planes, nrefl, w))
+        err = _ErrP()
+        L = _lib()
+        h = L.pc_transmission_efficiencies_from_totals(source._h, n, sw.ctypes.data_as(_dp), cnt.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                       sp, C.byref(err))
+        _check(err)
+        return cls(h, source)
+
     def write_hdf5(self, filename):
         err = _ErrP()
         _lib().polycap_transmission_efficiencies_write_hdf5(self._h, None if filename is None else str(filename).encode(), C.byref(err))

@@ -123,6 +123,13 @@ int polycap_photon_within_pc_boundary(double polycap_radius, polycap_vector3 pho
 POLYCAP_EXTERN int pc_optconst_scatf(unsigned int nelem, const int *iz, const double *wi, double density,
 	size_t n_energies, const double *energies, double *amu, double *scatf, int *synthetic, polycap_error **error);
 POLYCAP_EXTERN const char *pc_optconst_provider(void);
+/* name of the HDF5 shared library bound at run time by the result writer, or "none" */
+POLYCAP_EXTERN const char *pc_hdf5_provider(void);
+
+/* result object construction (pc_transeff.c) */
+polycap_transmission_efficiencies *pc_transeff_alloc(polycap_source *source, size_t np, const char *caller, polycap_error **error);
+void pc_transeff_plane_pointers(polycap_transmission_efficiencies *eff, pc_hip_images *dst);
+void pc_transeff_finish(polycap_transmission_efficiencies *eff, const double *sum_weights, const int64_t counters[6]);
 
 /* device context management */
 void pc_ctx_cache_clear(pc_ctx_cache *c);

@@ -357,41 +357,15 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 	}
 
 	const size_t ne = source->n_energies;
-	const size_t np = (size_t)n_photons;
-	polycap_transmission_efficiencies *eff = calloc(1, sizeof(*eff));
-	struct _polycap_images *img = calloc(1, sizeof(*img));
+	polycap_transmission_efficiencies *eff = pc_transeff_alloc(source, (size_t)n_photons, "polycap_source_get_transmission_efficiencies", error);
 	double *sum_weights = malloc(sizeof(double)*ne);
-	int alloc_ok = (eff != NULL && img != NULL && sum_weights != NULL);
-	if (alloc_ok) {
-		eff->images = img;
-		img = NULL;
-		eff->energies = malloc(sizeof(double)*ne);
-		eff->efficiencies = malloc(sizeof(double)*ne);
-		double **planes[] = { &eff->images->src_start_coords[0], &eff->images->src_start_coords[1],
-			&eff->images->pc_start_coords[0], &eff->images->pc_start_coords[1],
-			&eff->images->pc_start_dir[0], &eff->images->pc_start_dir[1],
-			&eff->images->pc_start_elecv[0], &eff->images->pc_start_elecv[1],
-			&eff->images->pc_exit_coords[0], &eff->images->pc_exit_coords[1], &eff->images->pc_exit_coords[2],
-			&eff->images->pc_exit_dir[0], &eff->images->pc_exit_dir[1],
-			&eff->images->pc_exit_elecv[0], &eff->images->pc_exit_elecv[1], &eff->images->pc_exit_dtravel };
-		alloc_ok = (eff->energies != NULL && eff->efficiencies != NULL);
-		for (size_t k = 0; k < sizeof(planes)/sizeof(planes[0]); k++) {
-			*planes[k] = malloc(sizeof(double)*np);
-			alloc_ok = alloc_ok && (*planes[k] != NULL);
-		}
-		eff->images->pc_exit_nrefl = malloc(sizeof(int64_t)*np);
-		eff->images->exit_coord_weights = malloc(sizeof(double)*np*ne);
-		alloc_ok = alloc_ok && eff->images->pc_exit_nrefl != NULL && eff->images->exit_coord_weights != NULL;
-	}
-	if (!alloc_ok) {
-		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_source_get_transmission_efficiencies: could not allocate memory for efficiencies -> %s", strerror(errno));
-		free(img);
+	if (eff == NULL || sum_weights == NULL) {
+		if (eff != NULL)
+			polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_source_get_transmission_efficiencies: could not allocate memory for efficiencies -> %s", strerror(errno));
 		free(sum_weights);
 		polycap_transmission_efficiencies_free(eff);
 		return NULL;
 	}
-	eff->source = source;
-	eff->n_energies = ne;
 
 	pc_hip_ctx *ctx = pc_ctx_for(&source->cache, description, ne, source->energies, source, "polycap_source_get_transmission_efficiencies", error);
 	if (ctx == NULL) {
@@ -414,20 +388,7 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 		status = pc_hip_transmission_totals(ctx, sum_weights, counters, NULL);
 	if (status == PC_HIP_OK) {
 		pc_hip_images dst;
-		memset(&dst, 0, sizeof(dst));
-		for (int k = 0; k < 2; k++) {
-			dst.src_start_coords[k] = eff->images->src_start_coords[k];
-			dst.pc_start_coords[k] = eff->images->pc_start_coords[k];
-			dst.pc_start_dir[k] = eff->images->pc_start_dir[k];
-			dst.pc_start_elecv[k] = eff->images->pc_start_elecv[k];
-			dst.pc_exit_dir[k] = eff->images->pc_exit_dir[k];
-			dst.pc_exit_elecv[k] = eff->images->pc_exit_elecv[k];
-		}
-		for (int k = 0; k < 3; k++)
-			dst.pc_exit_coords[k] = eff->images->pc_exit_coords[k];
-		dst.pc_exit_nrefl = eff->images->pc_exit_nrefl;
-		dst.pc_exit_dtravel = eff->images->pc_exit_dtravel;
-		dst.exit_coord_weights = eff->images->exit_coord_weights;
+		pc_transeff_plane_pointers(eff, &dst);
 		status = pc_hip_transmission_images(ctx, 0, n_photons, &dst);
 	}
 	if (status != PC_HIP_OK) {
@@ -445,13 +406,7 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 		(double)(sum_iexit+sum_not_transmitted)/(sum_iexit+sum_not_entered+sum_not_transmitted));
 	printf("iexit: %" PRId64 ", no enter: %" PRId64 ", no trans: %" PRId64 "\n", sum_iexit, sum_not_entered, sum_not_transmitted);
 
-	description->open_area = (double)(sum_iexit+sum_not_transmitted)/(sum_iexit+sum_not_entered+sum_not_transmitted);
-	eff->images->i_start = sum_iexit+sum_not_entered+sum_not_transmitted;
-	eff->images->i_exit = sum_iexit;
-	for (size_t i = 0; i < ne; i++) {
-		eff->energies[i] = source->energies[i];
-		eff->efficiencies[i] = (sum_weights[i] / ((double)sum_iexit+(double)sum_not_transmitted)) * description->open_area;
-	}
+	pc_transeff_finish(eff, sum_weights, counters);
 	free(sum_weights);
 	return eff;
 }

@@ -5,7 +5,7 @@
  * SoA image planes indexed by exit-photon slot, exit_coord_weights row-major by photon; getters hand out
  * malloc'd copies (caller frees with polycap_free).  Leak planes are absent (leak_calc is unsupported), so the
  * leak getters report "no leak events" exactly as the reference does for an empty list.
- * The HDF5 writer (reference :38-780) is outside this round's scope and reports POLYCAP_ERROR_UNSUPPORTED.
+ * The HDF5 writer (reference :38-780) lives in pc_hdf5.c.
  */
 #include "pc_private.h"
 
@@ -42,6 +42,114 @@ void polycap_transmission_efficiencies_free(polycap_transmission_efficiencies *e
 	free(efficiencies->efficiencies);
 	pc_images_free(efficiencies->images);
 	free(efficiencies);
+}
+
+/* result object with every plane allocated for np exit photons (reference: src/polycap-source.c:556-681) */
+polycap_transmission_efficiencies *pc_transeff_alloc(polycap_source *source, size_t np, const char *caller, polycap_error **error)
+{
+	const size_t ne = source->n_energies;
+	const size_t nalloc = np ? np : 1;
+	polycap_transmission_efficiencies *eff = calloc(1, sizeof(*eff));
+	int alloc_ok = (eff != NULL);
+	if (alloc_ok) {
+		eff->images = calloc(1, sizeof(*eff->images));
+		alloc_ok = (eff->images != NULL);
+	}
+	if (alloc_ok) {
+		struct _polycap_images *im = eff->images;
+		eff->energies = malloc(sizeof(double)*ne);
+		eff->efficiencies = malloc(sizeof(double)*ne);
+		double **planes[] = { &im->src_start_coords[0], &im->src_start_coords[1], &im->pc_start_coords[0], &im->pc_start_coords[1],
+			&im->pc_start_dir[0], &im->pc_start_dir[1], &im->pc_start_elecv[0], &im->pc_start_elecv[1],
+			&im->pc_exit_coords[0], &im->pc_exit_coords[1], &im->pc_exit_coords[2],
+			&im->pc_exit_dir[0], &im->pc_exit_dir[1], &im->pc_exit_elecv[0], &im->pc_exit_elecv[1], &im->pc_exit_dtravel };
+		alloc_ok = (eff->energies != NULL && eff->efficiencies != NULL);
+		for (size_t k = 0; k < sizeof(planes)/sizeof(planes[0]); k++) {
+			*planes[k] = calloc(nalloc, sizeof(double));
+			alloc_ok = alloc_ok && (*planes[k] != NULL);
+		}
+		im->pc_exit_nrefl = calloc(nalloc, sizeof(int64_t));
+		im->exit_coord_weights = calloc(nalloc*ne, sizeof(double));
+		alloc_ok = alloc_ok && im->pc_exit_nrefl != NULL && im->exit_coord_weights != NULL;
+	}
+	if (!alloc_ok) {
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "%s: could not allocate memory for efficiencies -> %s", caller, strerror(errno));
+		polycap_transmission_efficiencies_free(eff);
+		return NULL;
+	}
+	eff->source = source;
+	eff->n_energies = ne;
+	memcpy(eff->energies, source->energies, sizeof(double)*ne);
+	return eff;
+}
+
+void pc_transeff_plane_pointers(polycap_transmission_efficiencies *eff, pc_hip_images *dst)
+{
+	const struct _polycap_images *im = eff->images;
+	memset(dst, 0, sizeof(*dst));
+	for (int k = 0; k < 2; k++) {
+		dst->src_start_coords[k] = im->src_start_coords[k];
+		dst->pc_start_coords[k] = im->pc_start_coords[k];
+		dst->pc_start_dir[k] = im->pc_start_dir[k];
+		dst->pc_start_elecv[k] = im->pc_start_elecv[k];
+		dst->pc_exit_dir[k] = im->pc_exit_dir[k];
+		dst->pc_exit_elecv[k] = im->pc_exit_elecv[k];
+	}
+	for (int k = 0; k < 3; k++)
+		dst->pc_exit_coords[k] = im->pc_exit_coords[k];
+	dst->pc_exit_nrefl = im->pc_exit_nrefl;
+	dst->pc_exit_dtravel = im->pc_exit_dtravel;
+	dst->exit_coord_weights = im->exit_coord_weights;
+}
+
+/* totals -> open area, counts and efficiencies (reference: src/polycap-source.c:1061-1076) */
+void pc_transeff_finish(polycap_transmission_efficiencies *eff, const double *sum_weights, const int64_t counters[6])
+{
+	polycap_description *description = eff->source->description;
+	const int64_t sum_iexit = counters[0], sum_not_entered = counters[1], sum_not_transmitted = counters[2];
+	description->open_area = (double)(sum_iexit+sum_not_transmitted)/(sum_iexit+sum_not_entered+sum_not_transmitted);
+	eff->images->i_start = sum_iexit+sum_not_entered+sum_not_transmitted;
+	eff->images->i_exit = sum_iexit;
+	for (size_t i = 0; i < eff->n_energies; i++)
+		eff->efficiencies[i] = (sum_weights[i] / ((double)sum_iexit+(double)sum_not_transmitted)) * description->open_area;
+}
+
+void *pc_transmission_efficiencies_from_totals(void *source_, int64_t n_exit, const double *sum_weights, const int64_t counters[6],
+	const pc_hip_images *planes, void *error_)
+{
+	polycap_source *source = source_;
+	polycap_error **error = error_;
+	if (source == NULL || source->description == NULL || source->energies == NULL || source->n_energies < 1) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "pc_transmission_efficiencies_from_totals: source must hold a description and energies");
+		return NULL;
+	}
+	if (sum_weights == NULL || counters == NULL) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "pc_transmission_efficiencies_from_totals: sum_weights and counters cannot be NULL");
+		return NULL;
+	}
+	if (n_exit < 0 || counters[0] != n_exit || counters[1] < 0 || counters[2] < 0 || counters[0] + counters[2] < 1) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "pc_transmission_efficiencies_from_totals: counters[0] must equal n_exit and at least one photon must have entered");
+		return NULL;
+	}
+	polycap_transmission_efficiencies *eff = pc_transeff_alloc(source, (size_t)n_exit, "pc_transmission_efficiencies_from_totals", error);
+	if (eff == NULL)
+		return NULL;
+	if (planes != NULL && n_exit > 0) {
+		pc_hip_images own;
+		pc_transeff_plane_pointers(eff, &own);
+		const size_t n = (size_t)n_exit, ne = source->n_energies;
+#define PC_COPY(field, count) do { if (planes->field != NULL) memcpy(own.field, planes->field, sizeof(*own.field) * (count)); } while (0)
+		for (int k = 0; k < 2; k++) {
+			PC_COPY(src_start_coords[k], n); PC_COPY(pc_start_coords[k], n); PC_COPY(pc_start_dir[k], n);
+			PC_COPY(pc_start_elecv[k], n); PC_COPY(pc_exit_dir[k], n); PC_COPY(pc_exit_elecv[k], n);
+		}
+		for (int k = 0; k < 3; k++)
+			PC_COPY(pc_exit_coords[k], n);
+		PC_COPY(pc_exit_nrefl, n); PC_COPY(pc_exit_dtravel, n); PC_COPY(exit_coord_weights, n * ne);
+#undef PC_COPY
+	}
+	pc_transeff_finish(eff, sum_weights, counters);
+	return eff;
 }
 
 bool polycap_transmission_efficiencies_get_data(polycap_transmission_efficiencies *efficiencies, size_t *n_energies,
@@ -201,19 +309,5 @@ bool polycap_transmission_efficiencies_get_intleak_data(polycap_transmission_eff
 	if (n_leaks) *n_leaks = 0;
 	if (leaks) *leaks = NULL;
 	polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_getintleak_data: no intleak events in efficiencies");
-	return false;
-}
-
-bool polycap_transmission_efficiencies_write_hdf5(polycap_transmission_efficiencies *efficiencies, const char *filename, polycap_error **error)
-{
-	if (efficiencies == NULL) {
-		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_transmission_efficiencies_write_hdf5: efficiencies cannot be NULL");
-		return false;
-	}
-	if (filename == NULL) {
-		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_transmission_efficiencies_write_hdf5: filename cannot be NULL");
-		return false;
-	}
-	polycap_set_error_literal(error, POLYCAP_ERROR_UNSUPPORTED, "polycap_transmission_efficiencies_write_hdf5: the HDF5 writer is not part of the MI355X build yet; use the getters");
 	return false;
 }

@@ -138,18 +138,7 @@ class TraceContext:
         planes = np.zeros((17, count))
         nrefl = np.zeros(count, dtype=np.int64)
         w = np.zeros((count, ne))
-        s = _cabi.ImagesS()
-        order = [("src_start_coords", 2), ("pc_start_coords", 2), ("pc_start_dir", 2), ("pc_start_elecv", 2),
-                 ("pc_exit_coords", 3), ("pc_exit_dir", 2), ("pc_exit_elecv", 2)]
-        k = 0
-        for name, m in order:
-            arr = getattr(s, name)
-            for j in range(m):
-                arr[j] = dptr(planes[k])
-                k += 1
-        s.pc_exit_nrefl = nrefl.ctypes.data_as(c_int64_p)
-        s.pc_exit_dtravel = dptr(planes[16])
-        s.exit_coord_weights = dptr(w)
+        s = _cabi.images_struct(planes, nrefl, w)
         st = self._L.pc_hip_transmission_images(self._h, int(first), int(count), C.byref(s))
         if st != _cabi.PC_HIP_OK:
             raise HipError("pc_hip_transmission_images", st)

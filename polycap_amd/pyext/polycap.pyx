@@ -83,6 +83,20 @@ cdef extern from "polycap.h" nogil:
         polycap_vector3 **exit_coords, polycap_vector3 **exit_direction, polycap_vector3 **exit_elecv, int64_t **n_refl, double **d_travel,
         size_t *n_energies, double ***exit_weights, polycap_error **error)
 
+    ctypedef struct pc_hip_images:
+        double *src_start_coords[2]
+        double *pc_start_coords[2]
+        double *pc_start_dir[2]
+        double *pc_start_elecv[2]
+        double *pc_exit_coords[3]
+        double *pc_exit_dir[2]
+        double *pc_exit_elecv[2]
+        int64_t *pc_exit_nrefl
+        double *pc_exit_dtravel
+        double *exit_coord_weights
+    void *pc_transmission_efficiencies_from_totals(void *source, int64_t n_exit, const double *sum_weights, const int64_t *counters,
+        const pc_hip_images *planes, void *error)
+
     ctypedef struct polycap_progress_monitor
     ctypedef struct polycap_source
     polycap_source *polycap_source_new(polycap_description *description, double d_source, double src_x, double src_y, double src_sigx,
@@ -454,6 +468,13 @@ cdef class TransmissionEfficiencies:
     def exit_weights(self):
         return self._exit()[6]
 
+    @staticmethod
+    def from_totals(source, sum_weights, counters, images=None, exit_weights=None):
+        """Extension of this build (no reference counterpart): result object from totals, and optionally the
+        [n_exit, 17] image array + [n_exit, nE] weights of polycap_amd.TraceContext.images(), produced elsewhere
+        (several GPUs / ranks), so that the getters and write_hdf5 serve a sharded run too."""
+        return source._efficiencies_from_totals(sum_weights, counters, images, exit_weights)
+
     def write_hdf5(self, filename):
         cdef polycap_error *error = NULL
         cdef const char *fn = NULL
@@ -519,5 +540,50 @@ cdef class Source:
         _raise_if(error)
         cdef TransmissionEfficiencies t = TransmissionEfficiencies.__new__(TransmissionEfficiencies)
         t._eff = e
+        t._source = self
+        return t
+
+    def _efficiencies_from_totals(self, sum_weights, counters, images, exit_weights):
+        cdef polycap_error *error = NULL
+        cdef pc_hip_images im
+        cdef pc_hip_images *imp = NULL
+        cdef double[::1] sw = np.ascontiguousarray(sum_weights, dtype=np.float64).ravel()
+        cdef double[:, ::1] planes
+        cdef int64_t[::1] nrefl
+        cdef double[:, ::1] w
+        cnt_np = np.zeros(6, dtype=np.int64)
+        cc = np.asarray(counters, dtype=np.int64).ravel()
+        cnt_np[:min(6, cc.size)] = cc[:6]
+        cdef int64_t[::1] cnt = cnt_np
+        cdef int64_t n = cnt[0]
+        cdef int k
+        if images is not None:
+            img = np.asarray(images, dtype=np.float64)
+            if img.ndim != 2 or img.shape[0] != n or img.shape[1] != 17:
+                raise ValueError("images must have shape (counters[0], 17)")
+            wnp = np.zeros((n, sw.shape[0])) if exit_weights is None else np.ascontiguousarray(exit_weights, dtype=np.float64)
+            if wnp.ndim != 2 or wnp.shape[0] != n or wnp.shape[1] != sw.shape[0]:
+                raise ValueError("exit_weights must have shape (counters[0], n_energies)")
+            if n > 0:
+                planes = np.ascontiguousarray(img.T)
+                nrefl = np.ascontiguousarray(np.rint(img[:, 15]).astype(np.int64))
+                w = wnp
+                for k in range(2):
+                    im.src_start_coords[k] = &planes[k, 0]
+                    im.pc_start_coords[k] = &planes[2 + k, 0]
+                    im.pc_start_dir[k] = &planes[4 + k, 0]
+                    im.pc_start_elecv[k] = &planes[6 + k, 0]
+                    im.pc_exit_dir[k] = &planes[11 + k, 0]
+                    im.pc_exit_elecv[k] = &planes[13 + k, 0]
+                for k in range(3):
+                    im.pc_exit_coords[k] = &planes[8 + k, 0]
+                im.pc_exit_nrefl = &nrefl[0]
+                im.pc_exit_dtravel = &planes[16, 0]
+                im.exit_coord_weights = &w[0, 0]
+                imp = &im
+        cdef void *e = pc_transmission_efficiencies_from_totals(<void *> self._source, n, &sw[0], &cnt[0], imp, <void *> &error)
+        _raise_if(error)
+        cdef TransmissionEfficiencies t = TransmissionEfficiencies.__new__(TransmissionEfficiencies)
+        t._eff = <polycap_transmission_efficiencies *> e
         t._source = self
         return t

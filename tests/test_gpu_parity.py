@@ -299,6 +299,18 @@ def test_public_c_api_on_gpu(pa, oracle, known, binding):
     assert next(iter(eff.start_direction)) == (0., 0., 1.)
     with pytest.raises(ValueError):
         eff.write_hdf5(None)
+    # reference tests/source.c:280-290: the result of a real run goes to an HDF5 file; read back with h5dump where present
+    import os
+    import tempfile
+    from tests import test_hdf5_writer as H
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "run.h5")
+        eff.write_hdf5(path)
+        assert os.path.getsize(path) > 30000 * 17 * 8
+        if H.H5DUMP is not None:
+            assert np.array_equal(H._read(path, "/Transmission_Efficiencies", tmp), effs)
+            assert np.array_equal(H._read(path, "/PC_Exit/Weights", tmp).reshape(w.shape), w)
+            assert np.array_equal(H._read(path, "/PC_Exit/N_Reflections", tmp), eff.n_refl.astype(np.float64))
     photon = src.get_photon(capi.Rng(20000))
     assert abs(photon.start_coords[0]) <= 0.2065
 
