@@ -319,6 +319,8 @@ int orc_reflect(const orc_optic *optic, orc_photon *photon, orc_vec3 surface_nor
 	orc_vec3 electric_vector = {0., 0., 0.};
 
 	if (photon == NULL || optic == NULL) return -1;
+	if (photon->leak_calc)
+		return orc_reflect_leak(optic, photon, surface_norm);   /* polycap_oracle_leak.c */
 	/* :596-602 */
 	orc_norm(&surface_norm);
 	orc_norm(&photon->exit_direction);
@@ -456,7 +458,7 @@ int orc_trace(const orc_optic *optic, int *ix, orc_photon *photon, const double 
 
 /* ------------------------------------------------------------------ launch */
 
-/* src/polycap-photon.c:390-955, leak_calc=false.
+/* src/polycap-photon.c:390-955 (leak_calc = photon->leak_calc).
  * amu/scatf are supplied by the caller (the reference calls xraylib via polycap_photon_scatf
  * at :495 for every launch; the values depend only on composition and energy). */
 int orc_launch(const orc_optic *optic, orc_photon *photon, size_t n_energies, const double *energies,
@@ -549,6 +551,13 @@ int orc_launch(const orc_optic *optic, orc_photon *photon, size_t n_energies, co
 	}
 	d_ph_capcen = sqrt( (photon->start_coords.x-current_cap_x)*(photon->start_coords.x-current_cap_x) + (photon->start_coords.y-current_cap_y)*(photon->start_coords.y-current_cap_y) );
 	if (d_ph_capcen > current_cap_rad) {
+		if (photon->leak_calc) {
+			/* :645-887 */
+			int rc = orc_launch_in_wall_leak(optic, photon, cap_x, cap_y, ix);
+			free(cap_x);
+			free(cap_y);
+			return rc;
+		}
 		/* :888-906 (leak_calc=false): photon hit the glass at the entrance */
 		free(cap_x);
 		free(cap_y);
@@ -770,10 +779,10 @@ void orc_sample_photon_flat(const orc_optic *optic, const orc_source *source,
 
 /* src/polycap-source.c:744-966 for one exit-photon slot j; returns attempts used, or 0 if max_attempts ran out.
  * cnt[0..3] += {iexit, not_entered, not_transmitted, i_refl of the transmitted photon} */
-static uint32_t orc_one_slot(const orc_optic *optic, const orc_source *source,
-                             size_t n_energies, const double *energies, const double *amu, const double *scatf,
-                             uint64_t seed, int64_t j, uint32_t max_attempts,
-                             double *w, int64_t cnt[4], double *img)
+uint32_t orc_one_slot(const orc_optic *optic, const orc_source *source,
+                      size_t n_energies, const double *energies, const double *amu, const double *scatf,
+                      uint64_t seed, int64_t j, uint32_t max_attempts,
+                      double *w, int64_t cnt[4], double *img, orc_slot_leaks *sl)
 {
 	const double *z = optic->z, *ext = optic->ext;
 	const int nmax = optic->nmax;
@@ -787,6 +796,7 @@ static uint32_t orc_one_slot(const orc_optic *optic, const orc_source *source,
 	for (k = 0; k < max_attempts; k++) {
 		/* :748-750 */
 		orc_sample_photon(optic, source, seed, (uint64_t)j, k, &ph);
+		ph.leak_calc = (sl != NULL);
 		iesc = orc_launch(optic, &ph, n_energies, energies, amu, scatf, w);
 		/* :758-777 */
 		if (iesc == 0) cnt[2]++;
@@ -804,6 +814,8 @@ static uint32_t orc_one_slot(const orc_optic *optic, const orc_source *source,
 				iesc = orc_within_pc_boundary(ext[nmax], temp_vect);
 			}
 		}
+		if (sl != NULL)
+			orc_slot_leaks_collect(sl, &ph, iesc, k);   /* :799-879, polycap_oracle_leak.c */
 		if (iesc == 1)
 			break;
 	}
@@ -892,7 +904,7 @@ int orc_transmission(const orc_optic *optic, const orc_source *source,
 #endif
 			for (j = 0; j < n_slots; j++) {
 				uint32_t used = orc_one_slot(optic, source, n_energies, energies, amu, scatf, seed, slot0 + j,
-				                             max_attempts, w, pc, img ? img + 17*(size_t)j : NULL);
+				                             max_attempts, w, pc, img ? img + 17*(size_t)j : NULL, NULL);
 				if (used == 0) {
 #ifdef _OPENMP
 #pragma omp atomic write

@@ -45,7 +45,15 @@ typedef struct {
 	double d_source, src_x, src_y, src_sigx, src_sigy, src_shiftx, src_shifty, hor_pol;
 } orc_source;
 
-/* mutable photon state: src/polycap-private.h:124-145 (_polycap_photon), leak fields dropped */
+/* one leak event: include/polycap-photon.h:40-47 (struct _polycap_leak) */
+typedef struct {
+	orc_vec3 coords, direction, elecv;
+	int64_t n_refl;
+	size_t n_energies;
+	double *weight;
+} orc_leak;
+
+/* mutable photon state: src/polycap-private.h:124-145 (_polycap_photon) */
 typedef struct {
 	orc_vec3 start_coords, start_direction, start_electric_vector;
 	orc_vec3 exit_coords, exit_direction, exit_electric_vector;
@@ -57,6 +65,10 @@ typedef struct {
 	const double *scatf;
 	int64_t i_refl;
 	double d_travel;
+	/* leak_calc=true state (zero otherwise): the flag the reference passes as an argument, and the event lists */
+	int leak_calc;
+	orc_leak *extleak, *intleak;
+	int64_t n_extleak, n_intleak;
 } orc_photon;
 
 /* ---- helpers: src/polycap-photon.c:139-169, 365-386 ---- */
@@ -81,7 +93,17 @@ double orc_refl_polar(double e, double density, double scatf, double lin_abs_coe
 int    orc_reflect(const orc_optic *optic, orc_photon *photon, orc_vec3 surface_norm);
 int    orc_trace(const orc_optic *optic, int *ix, orc_photon *photon, const double *cap_x, const double *cap_y);
 
-/* ---- launch: src/polycap-photon.c:390-955 (leak_calc=false slice).
+/* ---- leak ("halo") path, polycap_oracle_leak.c.  orc_reflect / orc_launch take these branches when
+ * photon->leak_calc != 0 ---- */
+int  orc_pc_intersect(const orc_optic *optic, orc_vec3 photon_coord, orc_vec3 photon_direction, orc_vec3 *out);
+int  orc_trace_wall(const orc_optic *optic, orc_photon *photon, double *d_travel, int *r_cntr, int *q_cntr);
+int  orc_reflect_leak(const orc_optic *optic, orc_photon *photon, orc_vec3 surface_norm);
+int  orc_launch_in_wall_leak(const orc_optic *optic, orc_photon *photon, double *cap_x, double *cap_y, int *ix);
+void orc_leaks_free(orc_leak *list, int64_t n);
+void orc_photon_clear_leaks(orc_photon *photon);
+void orc_free(void *p);
+
+/* ---- launch: src/polycap-photon.c:390-955.
  * photon must have start_* set; weights[n_energies] is filled. Returns {1,0,2,-2,-1}. ---- */
 int orc_launch(const orc_optic *optic, orc_photon *photon, size_t n_energies, const double *energies,
                const double *amu, const double *scatf, double *weights);
@@ -92,6 +114,15 @@ int orc_launch_one(const orc_optic *optic, size_t n_energies, const double *ener
                    const double start_coords[3], const double start_dir[3], const double start_elecv[3],
                    double *weights, double exit_coords[3], double exit_dir[3], double exit_elecv[3],
                    int64_t *i_refl, double *d_travel);
+
+/* same with leak_calc=true: *ext_records / *int_records receive malloc'd arrays (free with orc_free) of
+ * n x (10 + n_energies) doubles: coords(3), direction(3), elecv(3), n_refl, weights[n_energies] */
+int orc_launch_one_leak(const orc_optic *optic, size_t n_energies, const double *energies,
+                        const double *amu, const double *scatf,
+                        const double start_coords[3], const double start_dir[3], const double start_elecv[3],
+                        double *weights, double exit_coords[3], double exit_dir[3], double exit_elecv[3],
+                        int64_t *i_refl, double *d_travel,
+                        double **ext_records, int64_t *n_ext, double **int_records, int64_t *n_int);
 
 /* batch of explicit photons, SoA in (start_xyz[3*n], dir[3*n], elecv[3*n]) AoS-by-photon layout;
  * outputs rc[n], weights[n*n_energies], exit_coords[3n], exit_dir[3n], exit_elecv[3n], i_refl[n], d_travel[n] */
@@ -124,6 +155,31 @@ int orc_transmission(const orc_optic *optic, const orc_source *source,
                      size_t n_energies, const double *energies, const double *amu, const double *scatf,
                      uint64_t seed, int64_t slot0, int64_t n_slots, int n_threads, uint32_t max_attempts,
                      double *sum_weights, int64_t counters[4], double *img, double *exit_weights);
+
+/* same driver with leak_calc=true (src/polycap-source.c:799-879, 925-1032).  Leak events come back as malloc'd arrays
+ * (orc_free) of n x (12 + n_energies) doubles: slot, attempt, then the record of orc_launch_one_leak; ordered by slot,
+ * and inside a slot as the reference orders them: events of the transmitted photon first, then those of the earlier
+ * attempts (launch return 0 or 2, or 1 outside the exit window) in attempt order. */
+int orc_transmission_leak(const orc_optic *optic, const orc_source *source,
+                          size_t n_energies, const double *energies, const double *amu, const double *scatf,
+                          uint64_t seed, int64_t slot0, int64_t n_slots, int n_threads, uint32_t max_attempts,
+                          double *sum_weights, int64_t counters[4], double *img, double *exit_weights,
+                          double **ext_records, int64_t *n_ext, double **int_records, int64_t *n_int);
+
+/* internals shared by the two driver files */
+typedef struct {
+	orc_leak *ext, *intl;            /* events of this slot in final order */
+	uint32_t *ext_attempt, *int_attempt;
+	int64_t n_ext, n_int;
+	orc_leak *ext_temp, *int_temp;   /* events of attempts that did not reach the exit window (:801-839) */
+	uint32_t *ext_temp_attempt, *int_temp_attempt;
+	int64_t n_ext_temp, n_int_temp;
+} orc_slot_leaks;
+void orc_slot_leaks_collect(orc_slot_leaks *sl, orc_photon *photon, int iesc, uint32_t attempt);
+uint32_t orc_one_slot(const orc_optic *optic, const orc_source *source,
+                      size_t n_energies, const double *energies, const double *amu, const double *scatf,
+                      uint64_t seed, int64_t j, uint32_t max_attempts,
+                      double *w, int64_t cnt[4], double *img, orc_slot_leaks *sl);
 
 /* efficiency formula src/polycap-source.c:1066-1076 */
 void orc_efficiencies(size_t n_energies, const double *sum_weights, const int64_t counters[4], double *eff);

@@ -33,19 +33,26 @@ class SourceS(C.Structure):
                                           "src_shiftx", "src_shifty", "hor_pol")]
 
 
+class LeakS(C.Structure):
+    _fields_ = [("coords", Vec3), ("direction", Vec3), ("elecv", Vec3), ("n_refl", C.c_int64),
+                ("n_energies", C.c_size_t), ("weight", c_double_p)]
+
+
 class PhotonS(C.Structure):
     _fields_ = [("start_coords", Vec3), ("start_direction", Vec3), ("start_electric_vector", Vec3),
                 ("exit_coords", Vec3), ("exit_direction", Vec3), ("exit_electric_vector", Vec3),
                 ("src_start_coords", Vec3),
                 ("n_energies", C.c_size_t), ("energies", c_double_p), ("weight", c_double_p),
                 ("amu", c_double_p), ("scatf", c_double_p),
-                ("i_refl", C.c_int64), ("d_travel", C.c_double)]
+                ("i_refl", C.c_int64), ("d_travel", C.c_double),
+                ("leak_calc", C.c_int), ("extleak", C.POINTER(LeakS)), ("intleak", C.POINTER(LeakS)),
+                ("n_extleak", C.c_int64), ("n_intleak", C.c_int64)]
 
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "polycap_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("polycap_oracle.c", "polycap_oracle_leak.c", "polycap_oracle.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -94,6 +101,19 @@ def lib():
         L.orc_transmission.restype = C.c_int
         L.orc_efficiencies.argtypes = [C.c_size_t, c_double_p, c_int64_p, c_double_p]
         L.orc_efficiencies.restype = None
+        L.orc_trace_wall.argtypes = [C.POINTER(OpticS), C.POINTER(PhotonS), c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_trace_wall.restype = C.c_int
+        L.orc_pc_intersect.argtypes = [C.POINTER(OpticS), Vec3, Vec3, C.POINTER(Vec3)]
+        L.orc_pc_intersect.restype = C.c_int
+        L.orc_photon_clear_leaks.argtypes = [C.POINTER(PhotonS)]
+        L.orc_photon_clear_leaks.restype = None
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_free.restype = None
+        pp, ip = C.POINTER(c_double_p), c_int64_p
+        L.orc_launch_one_leak.argtypes = L.orc_launch_one.argtypes + [pp, ip, pp, ip]
+        L.orc_launch_one_leak.restype = C.c_int
+        L.orc_transmission_leak.argtypes = L.orc_transmission.argtypes + [pp, ip, pp, ip]
+        L.orc_transmission_leak.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -174,6 +194,67 @@ def reflect(optic, photon, surface_norm):
     return lib().orc_reflect(C.byref(optic.s), C.byref(photon.s), vec(surface_norm))
 
 
+def trace_wall(optic, photon):
+    """polycap_capil_trace_wall on photon.s.exit_coords / exit_direction -> (rc, d_travel, r_cntr, q_cntr)"""
+    d = C.c_double(0)
+    r, q = C.c_int(0), C.c_int(0)
+    rc = lib().orc_trace_wall(C.byref(optic.s), C.byref(photon.s), C.byref(d), C.byref(r), C.byref(q))
+    return rc, d.value, r.value, q.value
+
+
+def pc_intersect(optic, coord, direction):
+    out = Vec3()
+    ok = lib().orc_pc_intersect(C.byref(optic.s), vec(coord), vec(direction), C.byref(out))
+    return out.tup() if ok else None
+
+
+def _leaks_of(ptr, n):
+    out = []
+    for k in range(n):
+        l = ptr[k]
+        out.append(dict(coords=l.coords.tup(), direction=l.direction.tup(), elecv=l.elecv.tup(), n_refl=int(l.n_refl),
+                        weights=np.ctypeslib.as_array(l.weight, shape=(l.n_energies,)).copy()))
+    return out
+
+
+def photon_leaks(photon):
+    """(extleak, intleak) lists of a Photon whose s.leak_calc was set before reflect()/trace()"""
+    return _leaks_of(photon.s.extleak, photon.s.n_extleak), _leaks_of(photon.s.intleak, photon.s.n_intleak)
+
+
+def photon_clear_leaks(photon):
+    lib().orc_photon_clear_leaks(C.byref(photon.s))
+
+
+def _records(ptr, n, stride):
+    a = np.ctypeslib.as_array(ptr, shape=(max(int(n), 1) * stride,))[:int(n) * stride].reshape(int(n), stride).copy()
+    lib().orc_free(C.cast(ptr, C.c_void_p))
+    return a
+
+
+LEAK_FIELDS = ("x", "y", "z", "dir_x", "dir_y", "dir_z", "elecv_x", "elecv_y", "elecv_z", "n_refl")
+
+
+def launch_one_leak(optic, energies, amu, scatf, start, direction, elecv):
+    """launch_one with leak_calc=true; ext / int = arrays [n, 10 + nE] (LEAK_FIELDS, then the weights)"""
+    E = np.ascontiguousarray(energies, dtype=np.float64)
+    A = np.ascontiguousarray(amu, dtype=np.float64)
+    S = np.ascontiguousarray(scatf, dtype=np.float64)
+    w = np.zeros_like(E)
+    st, di, ev = (np.ascontiguousarray(v, dtype=np.float64) for v in (start, direction, elecv))
+    ec, ed, ee = np.zeros(3), np.zeros(3), np.zeros(3)
+    ir = C.c_int64(0)
+    dt = C.c_double(0)
+    pe, pi = c_double_p(), c_double_p()
+    ne, ni = C.c_int64(0), C.c_int64(0)
+    rc = lib().orc_launch_one_leak(C.byref(optic.s), E.shape[0], _dp(E), _dp(A), _dp(S), _dp(st), _dp(di), _dp(ev),
+                                   _dp(w), _dp(ec), _dp(ed), _dp(ee), C.byref(ir), C.byref(dt),
+                                   C.byref(pe), C.byref(ne), C.byref(pi), C.byref(ni))
+    stride = 10 + E.shape[0]
+    return dict(rc=rc, weights=w, exit_coords=ec, exit_dir=ed, exit_elecv=ee, i_refl=ir.value, d_travel=dt.value,
+                ext=_records(pe, ne.value, stride), int=_records(pi, ni.value, stride))
+
+
 def trace(optic, ix, photon, cap_x, cap_y):
     cx = np.ascontiguousarray(cap_x, dtype=np.float64)
     cy = np.ascontiguousarray(cap_y, dtype=np.float64)
@@ -244,7 +325,8 @@ IMG_FIELDS = ("src_start_x", "src_start_y", "pc_start_x", "pc_start_y", "pc_star
 
 
 def transmission(optic, source, energies, amu, scatf, seed, slot0, n_slots, n_threads=0,
-                 max_attempts=1 << 20, images=False):
+                 max_attempts=1 << 20, images=False, leak_calc=False):
+    """leak_calc=True adds ext / int: arrays [n, 12 + nE] = slot, attempt, LEAK_FIELDS, weights"""
     E = np.ascontiguousarray(energies, dtype=np.float64)
     A = np.ascontiguousarray(amu, dtype=np.float64)
     S = np.ascontiguousarray(scatf, dtype=np.float64)
@@ -252,13 +334,20 @@ def transmission(optic, source, energies, amu, scatf, seed, slot0, n_slots, n_th
     cnt = np.zeros(4, dtype=np.int64)
     img = np.zeros((n_slots, 17)) if images else None
     ew = np.zeros((n_slots, E.shape[0])) if images else None
-    rc = lib().orc_transmission(C.byref(optic.s), C.byref(source), E.shape[0], _dp(E), _dp(A), _dp(S),
-                                seed, slot0, n_slots, n_threads, max_attempts,
-                                _dp(sw), cnt.ctypes.data_as(c_int64_p),
-                                _dp(img) if images else None, _dp(ew) if images else None)
+    args = (C.byref(optic.s), C.byref(source), E.shape[0], _dp(E), _dp(A), _dp(S),
+            seed, slot0, n_slots, n_threads, max_attempts, _dp(sw), cnt.ctypes.data_as(c_int64_p),
+            _dp(img) if images else None, _dp(ew) if images else None)
+    leaks = {}
+    if leak_calc:
+        pe, pi = c_double_p(), c_double_p()
+        ne, ni = C.c_int64(0), C.c_int64(0)
+        rc = lib().orc_transmission_leak(*args, C.byref(pe), C.byref(ne), C.byref(pi), C.byref(ni))
+        leaks = dict(ext=_records(pe, ne.value, 12 + E.shape[0]), int=_records(pi, ni.value, 12 + E.shape[0]))
+    else:
+        rc = lib().orc_transmission(*args)
     eff = np.zeros_like(E)
     if cnt[0] + cnt[1] + cnt[2] > 0:
         lib().orc_efficiencies(E.shape[0], _dp(sw), cnt.ctypes.data_as(c_int64_p), _dp(eff))
     return dict(rc=rc, sum_weights=sw, counters=cnt, efficiencies=eff, images=img, exit_weights=ew,
                 i_exit=int(cnt[0]), not_entered=int(cnt[1]), not_transmitted=int(cnt[2]), sum_irefl=int(cnt[3]),
-                i_start=int(cnt[0] + cnt[1] + cnt[2]))
+                i_start=int(cnt[0] + cnt[1] + cnt[2]), **leaks)
