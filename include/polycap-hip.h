@@ -73,7 +73,9 @@ POLYCAP_EXTERN int pc_hip_ctx_create(const pc_hip_problem *problem, int device, 
 POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
 
 /* Tuning / test switches: "literal_march" (1 = visit every segment with the reference's full quadratic,
- * 0 = certified skipping, default), "event_threshold" (lanes), "waves_per_cu", "block_size". */
+ * 0 = certified skipping, default), "event_threshold" (lanes), "blocks_per_cu", "block_size"; for leak runs
+ * "leak_max_depth" (stack frames per lane = walls one photon may cross), "leak_stack_mb" (HBM for those stacks),
+ * "leak_capacity" (leak record buffer, 0 = automatic; a run that outgrows it is repeated with a larger one). */
 POLYCAP_EXTERN int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value);
 
 /* polycap_photon_launch (src/polycap-photon.c:390-955, leak_calc=false) for n explicit photons.
@@ -103,6 +105,25 @@ POLYCAP_EXTERN int pc_hip_transmission_wait(pc_hip_ctx *ctx, float *kernel_ms);
 POLYCAP_EXTERN int pc_hip_transmission_totals(pc_hip_ctx *ctx, double *sum_weights, int64_t counters[6], uint64_t *sumw_fixed);
 /* Copies image planes of slots [first, first+count) (relative to slot0 of the last run) to the host. */
 POLYCAP_EXTERN int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const pc_hip_images *dst);
+
+/* ---- leak_calc = true ("halo" photons): src/polycap-capil.c:610-619, 657-1194, src/polycap-photon.c:171-362, 645-907,
+ * src/polycap-source.c:799-879, 925-1032.  Same calls with the fraction of every reflection that is transmitted through
+ * the glass followed as well; the leak events of the run are kept by the context until the next run.
+ * One event = PC_HIP_LEAK_HDR + n_energies doubles: slot (photon index for pc_hip_launch_photons_leak), attempt,
+ * coords xyz, direction xyz, electric vector xyz, n_refl, weights[n_energies] (struct _polycap_leak,
+ * include/polycap-photon.h:40-47).  Order = the reference's lists: by slot; inside a slot the events of the transmitted
+ * photon first, then those of the earlier attempts. */
+#define PC_HIP_LEAK_HDR 12
+POLYCAP_EXTERN int pc_hip_launch_photons_leak(pc_hip_ctx *ctx, int64_t n,
+	const double *start_coords, const double *start_dir, const double *start_elecv,
+	int32_t *rc, double *weights, double *exit_coords, double *exit_dir, double *exit_elecv,
+	int64_t *i_refl, double *d_travel);
+POLYCAP_EXTERN int pc_hip_transmission_run_leak(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64_t n_slots,
+	uint32_t max_attempts, int keep_images);
+/* number of extleak (left the optic through its side) / intleak (reached the exit plane inside the glass) events */
+POLYCAP_EXTERN int pc_hip_leak_counts(pc_hip_ctx *ctx, int64_t *n_ext, int64_t *n_int);
+/* events [first, first+count) of kind 0 (extleak) or 1 (intleak) into records[count * (PC_HIP_LEAK_HDR + n_energies)] */
+POLYCAP_EXTERN int pc_hip_leak_events(pc_hip_ctx *ctx, int kind, int64_t first, int64_t count, double *records);
 
 /* Scheduler statistics of the last transmission run (diagnostics): {march steps, march lane-steps, event phases,
  * event lanes, new phases, new lanes}, summed over all waves; lanes/phases = average active lanes per phase. */

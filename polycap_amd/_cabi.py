@@ -20,6 +20,7 @@ PC_HIP_ERR_INVALID = -2
 PC_HIP_ERR_RUNTIME = -3
 PC_HIP_ERR_MEMORY = -4
 PC_HIP_ERR_ATTEMPTS = -5
+PC_HIP_LEAK_HDR = 12   # doubles before the weights of one leak event (include/polycap-hip.h)
 
 
 class ProblemS(C.Structure):
@@ -114,6 +115,14 @@ def lib():
                                         P(C.c_int32), c_double_p, c_double_p, c_double_p, c_double_p,
                                         c_int64_p, c_double_p]
     L.pc_hip_launch_photons.restype = C.c_int
+    L.pc_hip_launch_photons_leak.argtypes = L.pc_hip_launch_photons.argtypes
+    L.pc_hip_launch_photons_leak.restype = C.c_int
+    L.pc_hip_transmission_run_leak.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_uint32, C.c_int]
+    L.pc_hip_transmission_run_leak.restype = C.c_int
+    L.pc_hip_leak_counts.argtypes = [C.c_void_p, c_int64_p, c_int64_p]
+    L.pc_hip_leak_counts.restype = C.c_int
+    L.pc_hip_leak_events.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, c_double_p]
+    L.pc_hip_leak_events.restype = C.c_int
     L.pc_hip_sample_photons.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, c_int64_p, P(C.c_uint32), c_double_p]
     L.pc_hip_sample_photons.restype = C.c_int
     L.pc_hip_transmission_run.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_uint32, C.c_int]

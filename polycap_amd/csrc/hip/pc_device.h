@@ -310,6 +310,12 @@ PC_HD int pc_launch_init(const pc_tables &T, const pc_params &Pm, pc_photon<NE> 
 	pc_norm3(dx, dy, dz);
 	ph.Px = x; ph.Py = y; ph.Pz = z;
 	ph.dx = dx; ph.dy = dy; ph.dz = dz;
+	/* polycap_refl_polar normalises the electric vector in place before its first use (src/polycap-capil.c:492-494);
+	 * the reflection algebra below relies on |E| = 1, so it is done here */
+	{
+		const double en = sqrt(ex*ex + ey*ey + ez*ez);
+		if (en != 1.) { ex /= en; ey /= en; ez /= en; }
+	}
 	ph.ex = ex; ph.ey = ey; ph.ez = ez;
 	ph.irefl = 0; ph.dtravel = 0.; ph.rc = 0; ph.C0 = 0.; ph.bnd = 0; ph.wset = 0;
 	/* NE == 0: weights live in memory and are initialised lazily (a photon without reflections has weight 1) */
@@ -612,9 +618,9 @@ PC_HD int pc_reflect_geom(const pc_photon<NE> &ph, double nx, double ny, double 
 	return 1;
 }
 
-/* one energy of src/polycap-capil.c:625-645: w *= rtot * r_rough.  Returns -1 on the reference's error exits,
- * else 1 when the new weight is still >= 1e-4, else 0. */
-PC_HD int pc_reflect_energy(const pc_energy_const &ec, const pc_refl_geom &g, double &w)
+/* Fresnel reflectivity rtot (polycap_refl_polar, src/polycap-capil.c:497-545) and roughness factor r_rough (:626-627) of
+ * one energy.  Returns -1 on the reference's error exits, else 0. */
+PC_HD int pc_fresnel(const pc_energy_const &ec, const pc_refl_geom &g, double &rtot, double &r_rough)
 {
 	if (ec.valid == 0.) return -1;
 	const double ct = g.alfa;
@@ -638,10 +644,19 @@ PC_HD int pc_reflect_energy(const pc_energy_const &ec, const pc_refl_geom &g, do
 	double pr = csr - ur, pi_ = csi - ui, er = csr + ur, ei = csi + ui;
 	double Np = fma(pr, pr, pi_*pi_), Dp = fma(er, er, ei*ei);
 	/* rtot = R_s frac_s + R_p frac_p = (es2 Ns Dp + ep2 Np Ds) / (sd2 Ds Dp): one division */
-	double rtot = fma(g.es2*Ns, Dp, g.ep2*Np*Ds) / (g.sd2*Ds*Dp);
+	rtot = fma(g.es2*Ns, Dp, g.ep2*Np*Ds) / (g.sd2*Ds*Dp);
 	if (rtot < 0. || rtot > 1.) return -1;                      /* :633-637 */
 	double cons1 = ec.rough_c*g.alfa;                           /* (1.01358*E)*alfa*sig_rough, :626 */
-	double r_rough = (ec.rough_c == 0.) ? 1.0 : exp(-1.*cons1*cons1);
+	r_rough = (ec.rough_c == 0.) ? 1.0 : exp(-1.*cons1*cons1);
+	return 0;
+}
+
+/* one energy of src/polycap-capil.c:625-645: w *= rtot * r_rough.  Returns -1 on the reference's error exits,
+ * else 1 when the new weight is still >= 1e-4, else 0. */
+PC_HD int pc_reflect_energy(const pc_energy_const &ec, const pc_refl_geom &g, double &w)
+{
+	double rtot, r_rough;
+	if (pc_fresnel(ec, g, rtot, r_rough) < 0) return -1;
 	w = w * rtot * r_rough;
 	return (w >= 1.e-4) ? 1 : 0;
 }

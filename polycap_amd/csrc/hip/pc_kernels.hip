@@ -23,6 +23,7 @@
 
 #include "polycap-hip.h"
 #include "pc_device.h"
+#include "pc_leak.h"
 #include "pc_problem.h"
 
 #ifndef PC_BLOCK
@@ -531,6 +532,26 @@ struct pc_hip_ctx {
 	long long run_slots = 0;
 	int run_pending = 0;
 	float last_ms = 0.f;
+	/* leak_calc=true runs (pc_leak_kernels.h) */
+	int leak_max_depth = 0;                /* frames per lane; default 2*n_shells + 16 (one frame per wall crossed) */
+	size_t leak_stack_bytes = (size_t)8 << 30;
+	long long leak_capacity = 0;           /* record buffer size of the next run; 0 = 8 per slot, grown on demand */
+	long long leak_capacity_used = 0;
+	double *d_leak_frames = nullptr;
+	size_t leak_frames_elems = 0;
+	double *d_leak_records = nullptr;
+	size_t leak_records_elems = 0;
+	unsigned long long *d_leak_cursor = nullptr;
+	double *d_amu = nullptr;
+	unsigned int *d_leak_attempts = nullptr;
+	long long leak_attempt_slots = 0;
+	int leak_pending = 0;                  /* a leak transmission run is in flight: wait() collects its events */
+	unsigned long long leak_seed = 0;
+	long long leak_slot0 = 0, leak_n_slots = 0;
+	unsigned int leak_max_attempts = 0;
+	int leak_keep_images = 0;
+	std::vector<double> leak_ext, leak_int;   /* events of the last leak run, PC_HIP_LEAK_HDR + n_energies doubles each */
+	long long leak_n_ext = 0, leak_n_int = 0;
 };
 
 static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
@@ -594,6 +615,10 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 	return PC_HIP_OK;
 }
 
+#include "pc_leak_kernels.h"
+
+static int pc_transmission_enqueue_leak(pc_hip_ctx *ctx);
+
 extern "C" {
 
 int pc_hip_device_count(void)
@@ -621,6 +646,11 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->d_img) (void)hipFree(ctx->d_img);
 	if (ctx->d_stage) (void)hipFree(ctx->d_stage);
 	if (ctx->d_wscratch) (void)hipFree(ctx->d_wscratch);
+	if (ctx->d_leak_frames) (void)hipFree(ctx->d_leak_frames);
+	if (ctx->d_leak_records) (void)hipFree(ctx->d_leak_records);
+	if (ctx->d_leak_cursor) (void)hipFree(ctx->d_leak_cursor);
+	if (ctx->d_amu) (void)hipFree(ctx->d_amu);
+	if (ctx->d_leak_attempts) (void)hipFree(ctx->d_leak_attempts);
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -670,6 +700,7 @@ int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ou
 		PC_CTX_CHECK(hipMalloc(&ctx->d_ec_soa, soa.size()*sizeof(double)));
 		PC_CTX_CHECK(hipMemcpy(ctx->d_ec_soa, soa.data(), soa.size()*sizeof(double), hipMemcpyHostToDevice));
 	}
+	ctx->leak_max_depth = (int)std::min(65536.0, 2.0*ctx->host.pm.n_shells + 16.0);
 	ctx->totals_bytes = sizeof(pc_totals) + 2*ctx->host.ec.size()*sizeof(unsigned long long);
 	PC_CTX_CHECK(hipMalloc(&ctx->d_totals, ctx->totals_bytes));
 	PC_CTX_CHECK(hipMemset(ctx->d_totals, 0, ctx->totals_bytes));
@@ -688,13 +719,16 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "march_burst") { if (value < 1) return pc_fail(PC_HIP_ERR_INVALID, "march_burst must be >= 1"); ctx->march_burst = (int)value; }
 	else if (n == "block_size") { if (value < 64 || value > PC_BLOCK || (value % 64) != 0) return pc_fail(PC_HIP_ERR_INVALID, "block_size must be a multiple of 64 up to the compiled maximum"); ctx->block_size = (int)value; }
 	else if (n == "blocks_per_cu") { if (value < 1 || value > 8) return pc_fail(PC_HIP_ERR_INVALID, "blocks_per_cu must be in [1,8]"); ctx->blocks_per_cu = (int)value; }
+	else if (n == "leak_max_depth") { if (value < 2 || value > (1 << 20)) return pc_fail(PC_HIP_ERR_INVALID, "leak_max_depth must be in [2, 2^20]"); ctx->leak_max_depth = (int)value; }
+	else if (n == "leak_stack_mb") { if (value < 1) return pc_fail(PC_HIP_ERR_INVALID, "leak_stack_mb must be >= 1"); ctx->leak_stack_bytes = (size_t)value << 20; }
+	else if (n == "leak_capacity") { if (value < 0) return pc_fail(PC_HIP_ERR_INVALID, "leak_capacity must be >= 0"); ctx->leak_capacity = (long long)value; }
 	else return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_set_option: unknown option " + n);
 	return PC_HIP_OK;
 }
 
-int pc_hip_launch_photons(pc_hip_ctx *ctx, int64_t n, const double *start_coords, const double *start_dir, const double *start_elecv,
-                          int32_t *rc, double *weights, double *exit_coords, double *exit_dir, double *exit_elecv,
-                          int64_t *i_refl, double *d_travel)
+static int pc_launch_photons_impl(pc_hip_ctx *ctx, int64_t n, const double *start_coords, const double *start_dir, const double *start_elecv,
+                                  int32_t *rc, double *weights, double *exit_coords, double *exit_dir, double *exit_elecv,
+                                  int64_t *i_refl, double *d_travel, int leak)
 {
 	if (!ctx || n < 0 || !start_coords || !start_dir || !start_elecv || !rc || !weights || !exit_coords || !exit_dir || !exit_elecv || !i_refl || !d_travel)
 		return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_launch_photons: NULL argument");
@@ -724,8 +758,25 @@ int pc_hip_launch_photons(pc_hip_ctx *ctx, int64_t n, const double *start_coords
 		a.in_start = d_start; a.in_dir = d_dir; a.in_elecv = d_ev;
 		a.out_rc = d_rc; a.out_weights = d_w; a.out_exit_coords = d_ec; a.out_exit_dir = d_ed; a.out_exit_elecv = d_ee;
 		a.out_irefl = d_ir; a.out_dtravel = d_dt;
-		status = pc_launch_kernel<PC_MODE_EXPLICIT>(ctx, a, n);
-		if (status) goto done;
+		if (leak) {
+			/* polycap_photon_launch(..., leak_calc=true): rerun with a larger record buffer until every event fits */
+			long long capacity = ctx->leak_capacity > 0 ? ctx->leak_capacity : std::max<long long>(4096, 16*n);
+			ctx->leak_slot0 = 0;
+			for (;;) {
+				ctx->leak_capacity_used = capacity;
+				status = pc_leak_enqueue<PC_MODE_EXPLICIT>(ctx, a, n, capacity);
+				if (status) goto done;
+				PC_LP_CHECK(hipStreamSynchronize(ctx->stream));
+				long long needed = 0;
+				status = pc_leak_collect(ctx, n, true, &needed);
+				if (status == 1) { capacity = needed + needed/4 + 1024; status = PC_HIP_OK; continue; }
+				if (status) goto done;
+				break;
+			}
+		} else {
+			status = pc_launch_kernel<PC_MODE_EXPLICIT>(ctx, a, n);
+			if (status) goto done;
+		}
 		PC_LP_CHECK(hipMemcpyAsync(rc, d_rc, N*sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
 		PC_LP_CHECK(hipMemcpyAsync(weights, d_w, N*ne*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 		PC_LP_CHECK(hipMemcpyAsync(exit_coords, d_ec, 3*N*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -734,12 +785,33 @@ int pc_hip_launch_photons(pc_hip_ctx *ctx, int64_t n, const double *start_coords
 		PC_LP_CHECK(hipMemcpyAsync(i_refl, d_ir, N*sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
 		PC_LP_CHECK(hipMemcpyAsync(d_travel, d_dt, N*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 		PC_LP_CHECK(hipStreamSynchronize(ctx->stream));
+		/* The kernels work with the normalised electric vector (polycap_refl_polar normalises it in place at the first
+		 * reflection, src/polycap-capil.c:492-494); a photon that never reached a reflection keeps the caller's vector */
+		for (size_t j = 0; j < N; j++) {
+			const bool untouched = (rc[j] == -2) || (!leak && (rc[j] == 2 || (rc[j] == 1 && i_refl[j] == 0)));
+			if (untouched)
+				for (int c = 0; c < 3; c++) exit_elecv[3*j + c] = start_elecv[3*j + c];
+		}
 	}
 done:
 #undef PC_LP_CHECK
 	(void)hipFree(d);
 	ctx->img_valid = 0;
 	return status;
+}
+
+int pc_hip_launch_photons(pc_hip_ctx *ctx, int64_t n, const double *start_coords, const double *start_dir, const double *start_elecv,
+                          int32_t *rc, double *weights, double *exit_coords, double *exit_dir, double *exit_elecv,
+                          int64_t *i_refl, double *d_travel)
+{
+	return pc_launch_photons_impl(ctx, n, start_coords, start_dir, start_elecv, rc, weights, exit_coords, exit_dir, exit_elecv, i_refl, d_travel, 0);
+}
+
+int pc_hip_launch_photons_leak(pc_hip_ctx *ctx, int64_t n, const double *start_coords, const double *start_dir, const double *start_elecv,
+                               int32_t *rc, double *weights, double *exit_coords, double *exit_dir, double *exit_elecv,
+                               int64_t *i_refl, double *d_travel)
+{
+	return pc_launch_photons_impl(ctx, n, start_coords, start_dir, start_elecv, rc, weights, exit_coords, exit_dir, exit_elecv, i_refl, d_travel, 1);
 }
 
 int pc_hip_sample_photons(pc_hip_ctx *ctx, uint64_t seed, int64_t n, const int64_t *slots, const uint32_t *attempts, double *out)
@@ -806,11 +878,54 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 	return PC_HIP_OK;
 }
 
+int pc_hip_transmission_run_leak(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64_t n_slots, uint32_t max_attempts, int keep_images)
+{
+	if (!ctx) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_run_leak: ctx must not be NULL");
+	if (n_slots < 1 || slot0 < 0) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_run_leak: n_slots must be >= 1 and slot0 >= 0");
+	if (max_attempts < 1) max_attempts = 1;
+	PC_HIP_CHECK(hipSetDevice(ctx->device));
+	const size_t ne = (size_t)ctx->host.pm.n_energies;
+	ctx->img_valid = 0;
+	if (keep_images && ctx->img_slots < n_slots) {
+		if (ctx->d_img) PC_HIP_CHECK(hipFree(ctx->d_img));
+		ctx->d_img = nullptr; ctx->img_slots = 0;
+		size_t bytes = ((size_t)PC_N_PLANES + ne) * (size_t)n_slots * sizeof(double);
+		if (hipMalloc(&ctx->d_img, bytes) != hipSuccess)
+			return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_run_leak: could not allocate the image planes; use keep_images=0");
+		ctx->img_slots = n_slots;
+	}
+	ctx->leak_seed = seed; ctx->leak_slot0 = slot0; ctx->leak_n_slots = n_slots;
+	ctx->leak_max_attempts = max_attempts; ctx->leak_keep_images = keep_images ? 1 : 0;
+	ctx->leak_capacity_used = ctx->leak_capacity > 0 ? ctx->leak_capacity : std::max<long long>(65536, 8*n_slots);
+	int status = pc_transmission_enqueue_leak(ctx);
+	if (status) return status;
+	ctx->run_slots = n_slots;
+	ctx->run_pending = 1;
+	ctx->leak_pending = 1;
+	ctx->img_valid = keep_images ? 1 : 0;
+	return PC_HIP_OK;
+}
+
 int pc_hip_transmission_wait(pc_hip_ctx *ctx, float *kernel_ms)
 {
 	if (!ctx) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_wait: ctx must not be NULL");
 	PC_HIP_CHECK(hipSetDevice(ctx->device));
 	PC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	while (ctx->leak_pending) {
+		/* leak run: fetch and order its events; a run that outgrew the record buffer is repeated with a larger one
+		 * (the photon streams are counter-based, so the repetition is the same run) */
+		long long needed = 0;
+		int st = pc_leak_collect(ctx, ctx->leak_n_slots, false, &needed);
+		if (st == 1) {
+			ctx->leak_capacity_used = needed + needed/4 + 1024;
+			st = pc_transmission_enqueue_leak(ctx);
+			if (st) { ctx->leak_pending = 0; ctx->run_pending = 0; return st; }
+			PC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+			continue;
+		}
+		ctx->leak_pending = 0;
+		if (st) { ctx->run_pending = 0; return st; }
+	}
 	if (ctx->run_pending) {
 		float ms = 0.f;
 		PC_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -818,6 +933,30 @@ int pc_hip_transmission_wait(pc_hip_ctx *ctx, float *kernel_ms)
 		ctx->run_pending = 0;
 	}
 	if (kernel_ms) *kernel_ms = ctx->last_ms;
+	return PC_HIP_OK;
+}
+
+int pc_hip_leak_counts(pc_hip_ctx *ctx, int64_t *n_ext, int64_t *n_int)
+{
+	if (!ctx) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_leak_counts: ctx must not be NULL");
+	int st = pc_hip_transmission_wait(ctx, nullptr);
+	if (st) return st;
+	if (n_ext) *n_ext = ctx->leak_n_ext;
+	if (n_int) *n_int = ctx->leak_n_int;
+	return PC_HIP_OK;
+}
+
+int pc_hip_leak_events(pc_hip_ctx *ctx, int kind, int64_t first, int64_t count, double *records)
+{
+	if (!ctx || (count > 0 && !records)) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_leak_events: NULL argument");
+	if (kind != 0 && kind != 1) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_leak_events: kind must be 0 (extleak) or 1 (intleak)");
+	int st = pc_hip_transmission_wait(ctx, nullptr);
+	if (st) return st;
+	const std::vector<double> &src = kind == 0 ? ctx->leak_ext : ctx->leak_int;
+	const long long have = kind == 0 ? ctx->leak_n_ext : ctx->leak_n_int;
+	if (first < 0 || count < 0 || first + count > have) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_leak_events: range out of bounds");
+	const size_t stride = PC_HIP_LEAK_HDR + (size_t)ctx->host.pm.n_energies;
+	if (count) memcpy(records, src.data() + (size_t)first*stride, (size_t)count*stride*sizeof(double));
 	return PC_HIP_OK;
 }
 
@@ -910,3 +1049,14 @@ void pc_hip_efficiencies(size_t n_energies, const double *sum_weights, const int
 }
 
 } /* extern "C" */
+
+static int pc_transmission_enqueue_leak(pc_hip_ctx *ctx)
+{
+	pc_kargs a;
+	pc_fill_common(ctx, a);
+	a.img = ctx->leak_keep_images ? ctx->d_img : nullptr;
+	a.seed = ctx->leak_seed; a.slot0 = ctx->leak_slot0; a.n_slots = ctx->leak_n_slots;
+	a.max_attempts = ctx->leak_max_attempts; a.keep_images = ctx->leak_keep_images;
+	return ctx->host.pm.generic_src ? pc_leak_enqueue<PC_MODE_SRC_GENERIC>(ctx, a, ctx->leak_n_slots, ctx->leak_capacity_used)
+	                                : pc_leak_enqueue<PC_MODE_SRC_CIRCULAR>(ctx, a, ctx->leak_n_slots, ctx->leak_capacity_used);
+}

@@ -30,6 +30,7 @@ struct pc_host_tables {
 	std::vector<double> z, cap, zh, cap2, hexd, idz, ext;
 	std::vector<float> mb1, md1, mb2, md2;   /* block-certificate tables for strides PC_L1, PC_L2 */
 	std::vector<pc_energy_const> ec;
+	std::vector<double> amu;                 /* linear attenuation coefficient per energy (leak path) */
 	pc_params pm;
 };
 
@@ -120,8 +121,10 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 	pm.bnd_thresh = ratio + 1e-9;
 
 	t.ec.resize(p->n_energies);
+	t.amu.clear();
 	for (size_t k = 0; k < p->n_energies; k++) {
 		double e = p->energies[k], scatf = p->scatf[k], amu = p->amu[k];
+		t.amu.push_back(amu);
 		pc_energy_const &c = t.ec[k];
 		double alfa = (PC_HC/e)*(PC_HC/e)*((PC_N_AVOG*PC_R0*p->density)/(2*PC_PI)) * scatf;
 		double beta = (PC_HC)/(4.*PC_PI) * (amu/e);

@@ -65,7 +65,8 @@ class TraceContext:
             raise HipError("pc_hip_set_option", st)
 
     # -- polycap_photon_launch for a batch of explicit photons
-    def launch_photons(self, start, direction, elecv):
+    def launch_photons(self, start, direction, elecv, leak_calc=False):
+        """leak_calc=True: polycap_photon_launch(..., leak_calc=true); the events are then available from leaks()"""
         st_ = np.ascontiguousarray(start, dtype=np.float64).reshape(-1, 3)
         di = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
         ev = np.ascontiguousarray(elecv, dtype=np.float64).reshape(-1, 3)
@@ -76,11 +77,12 @@ class TraceContext:
         ec, ed, ee = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 3))
         ir = np.zeros(n, dtype=np.int64)
         dt = np.zeros(n)
-        st = self._L.pc_hip_launch_photons(self._h, n, dptr(st_), dptr(di), dptr(ev),
-                                           rc.ctypes.data_as(C.POINTER(C.c_int32)), dptr(w), dptr(ec), dptr(ed), dptr(ee),
-                                           ir.ctypes.data_as(c_int64_p), dptr(dt))
+        fn = self._L.pc_hip_launch_photons_leak if leak_calc else self._L.pc_hip_launch_photons
+        st = fn(self._h, n, dptr(st_), dptr(di), dptr(ev),
+                rc.ctypes.data_as(C.POINTER(C.c_int32)), dptr(w), dptr(ec), dptr(ed), dptr(ee),
+                ir.ctypes.data_as(c_int64_p), dptr(dt))
         if st != _cabi.PC_HIP_OK:
-            raise HipError("pc_hip_launch_photons", st)
+            raise HipError("pc_hip_launch_photons_leak" if leak_calc else "pc_hip_launch_photons", st)
         return dict(rc=rc, weights=w, exit_coords=ec, exit_dir=ed, exit_elecv=ee, i_refl=ir, d_travel=dt)
 
     # -- polycap_source_get_photon on the device
@@ -96,11 +98,30 @@ class TraceContext:
         return out
 
     # -- polycap_source_get_transmission_efficiencies for a slot range
-    def run(self, seed, slot0, n_slots, max_attempts=1 << 20, keep_images=False):
-        st = self._L.pc_hip_transmission_run(self._h, int(seed), int(slot0), int(n_slots), int(max_attempts), int(bool(keep_images)))
+    def run(self, seed, slot0, n_slots, max_attempts=1 << 20, keep_images=False, leak_calc=False):
+        fn = self._L.pc_hip_transmission_run_leak if leak_calc else self._L.pc_hip_transmission_run
+        st = fn(self._h, int(seed), int(slot0), int(n_slots), int(max_attempts), int(bool(keep_images)))
         if st != _cabi.PC_HIP_OK:
-            raise HipError("pc_hip_transmission_run", st)
+            raise HipError("pc_hip_transmission_run_leak" if leak_calc else "pc_hip_transmission_run", st)
         self._last_n = int(n_slots)
+
+    def leaks(self):
+        """(ext, int): the leak events of the last leak_calc run, arrays [n, 12 + nE] with columns slot, attempt,
+        x, y, z, dir x y z, elecv x y z, n_refl, weights; in the reference's list order."""
+        ne_, ni_ = C.c_int64(0), C.c_int64(0)
+        st = self._L.pc_hip_leak_counts(self._h, C.byref(ne_), C.byref(ni_))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_leak_counts", st)
+        out = []
+        stride = _cabi.PC_HIP_LEAK_HDR + self.problem.n_energies
+        for kind, n in ((0, ne_.value), (1, ni_.value)):
+            a = np.zeros((n, stride))
+            if n:
+                st = self._L.pc_hip_leak_events(self._h, kind, 0, n, dptr(a))
+                if st != _cabi.PC_HIP_OK:
+                    raise HipError("pc_hip_leak_events", st)
+            out.append(a)
+        return out[0], out[1]
 
     def wait(self):
         ms = C.c_float(0)
@@ -145,15 +166,17 @@ class TraceContext:
         planes[15] = nrefl
         return dict(images=planes.T.copy(), exit_weights=w, nrefl=nrefl)
 
-    def transmission(self, seed, slot0, n_slots, max_attempts=1 << 20, keep_images=False):
-        """run + wait + totals (+ images) in one call."""
-        self.run(seed, slot0, n_slots, max_attempts, keep_images)
+    def transmission(self, seed, slot0, n_slots, max_attempts=1 << 20, keep_images=False, leak_calc=False):
+        """run + wait + totals (+ images, + leak events) in one call."""
+        self.run(seed, slot0, n_slots, max_attempts, keep_images, leak_calc)
         ms = self.wait()
         r = self.totals()
         r["kernel_ms"] = ms
         r["efficiencies"] = efficiencies(r["sum_weights"], r["counters"])
         if keep_images:
             r.update(self.images(0, n_slots))
+        if leak_calc:
+            r["ext"], r["int"] = self.leaks()
         return r
 
 

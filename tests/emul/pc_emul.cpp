@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "pc_problem.h"
+#include "pc_leak.h"
 
 namespace {
 
@@ -87,6 +88,94 @@ int emul_launch_batch(const pc_hip_problem *p, int literal, int use_regs, int64_
 		i_refl[j] = ir;
 		d_travel[j] = dt;
 	}
+	return 0;
+}
+
+/* polycap_photon_launch with leak_calc=true for explicit photons; records: capacity x (14 + n_energies) doubles */
+int emul_launch_leak(const pc_hip_problem *p, int literal, int64_t n,
+                     const double *start, const double *dir, const double *elecv, int max_depth, int64_t capacity,
+                     int32_t *rc, double *weights, double *exit_coords, double *exit_dir, double *exit_elecv,
+                     int64_t *i_refl, double *d_travel, double *records, int64_t *n_records, int32_t *stack_overflow)
+{
+	Emul E;
+	int r = setup(p, literal, E);
+	if (r) return r;
+	const int ne = (int)p->n_energies;
+	std::vector<double> frames((size_t)max_depth * (PC_LF_HDR + ne));
+	unsigned long long cursor = 0;
+	pc_leak_ctx cx;
+	cx.ec = E.t.ec.data(); cx.amu = E.t.amu.data(); cx.ne = ne;
+	cx.frames = frames.data(); cx.max_depth = max_depth;
+	cx.sink.records = records; cx.sink.cursor = &cursor; cx.sink.capacity = capacity;
+	cx.stack_overflow = 0;
+	for (int64_t j = 0; j < n; j++) {
+		const double *s = start + 3*j, *d = dir + 3*j, *e = elecv + 3*j;
+		pc_photon<0> ph; ph.wmem = nullptr; ph.wstride = 1;
+		int st = pc_launch_init(E.T, E.t.pm, ph, s[0], s[1], s[2], d[0], d[1], d[2], e[0], e[1], e[2]);
+		cx.slot = (double)j; cx.attempt = 0.;
+		rc[j] = pc_leak_launch(E.T, E.t.pm, cx, ph, st, s[2]);
+		for (int k = 0; k < ne; k++) weights[(size_t)j*ne + k] = frames[PC_LF_HDR + k];
+		exit_coords[3*j] = ph.Px; exit_coords[3*j+1] = ph.Py; exit_coords[3*j+2] = ph.Pz;
+		exit_dir[3*j] = ph.dx; exit_dir[3*j+1] = ph.dy; exit_dir[3*j+2] = ph.dz;
+		exit_elecv[3*j] = ph.ex; exit_elecv[3*j+1] = ph.ey; exit_elecv[3*j+2] = ph.ez;
+		i_refl[j] = ph.irefl;
+		d_travel[j] = ph.dtravel;
+	}
+	*n_records = (int64_t)cursor;
+	*stack_overflow = cx.stack_overflow;
+	return 0;
+}
+
+/* the driver loop of src/polycap-source.c:744-884 with leak_calc=true for slots [slot0, slot0 + n_slots):
+ * counters = {iexit, not_entered, not_transmitted, sum_irefl}; exit_weights [n_slots x n_energies] */
+int emul_transmission_leak(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int64_t n_slots, uint32_t max_attempts,
+                           int max_depth, int64_t capacity, double *sum_weights, int64_t *counters, double *exit_weights,
+                           double *records, int64_t *n_records, int32_t *stack_overflow)
+{
+	Emul E;
+	int r = setup(p, 0, E);
+	if (r) return r;
+	const int ne = (int)p->n_energies;
+	std::vector<double> frames((size_t)max_depth * (PC_LF_HDR + ne));
+	unsigned long long cursor = 0;
+	pc_leak_ctx cx;
+	cx.ec = E.t.ec.data(); cx.amu = E.t.amu.data(); cx.ne = ne;
+	cx.frames = frames.data(); cx.max_depth = max_depth;
+	cx.sink.records = records; cx.sink.cursor = &cursor; cx.sink.capacity = capacity;
+	cx.stack_overflow = 0;
+	for (int k = 0; k < ne; k++) sum_weights[k] = 0.;
+	for (int k = 0; k < 4; k++) counters[k] = 0;
+	for (int64_t j = 0; j < n_slots; j++) {
+		for (uint32_t attempt = 0; attempt < max_attempts; attempt++) {
+			pc_start s;
+			if (E.t.pm.generic_src) pc_sample_photon<true>(E.t.pm, seed, (uint64_t)(slot0 + j), attempt, s);
+			else pc_sample_photon<false>(E.t.pm, seed, (uint64_t)(slot0 + j), attempt, s);
+			pc_photon<0> ph; ph.wmem = nullptr; ph.wstride = 1;
+			int st = pc_launch_init(E.T, E.t.pm, ph, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez);
+			cx.slot = (double)(slot0 + j); cx.attempt = (double)attempt;
+			int rc = pc_leak_launch(E.T, E.t.pm, cx, ph, st, s.z);
+			int ok = 0;
+			if (rc == 0) counters[2]++;
+			else if (rc == 2) counters[1]++;
+			else if (rc == 1) {
+				ok = pc_in_exit_window(E.t.pm, ph);
+				if (!ok) {
+					/* reclassified as not transmitted by the driver (:762-777): its events wait like those of rc 0 */
+				}
+			}
+			if (ok) {
+				counters[0]++;
+				counters[3] += ph.irefl;
+				for (int k = 0; k < ne; k++) {
+					sum_weights[k] += frames[PC_LF_HDR + k];
+					if (exit_weights) exit_weights[(size_t)j*ne + k] = frames[PC_LF_HDR + k];
+				}
+				break;
+			}
+		}
+	}
+	*n_records = (int64_t)cursor;
+	*stack_overflow = cx.stack_overflow;
 	return 0;
 }
 

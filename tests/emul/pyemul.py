@@ -18,7 +18,8 @@ def lib():
         so = os.path.join(_HERE, "libpc_emul.so")
         srcs = [os.path.join(_HERE, "pc_emul.cpp"),
                 os.path.join(_ROOT, "polycap_amd", "csrc", "hip", "pc_device.h"),
-                os.path.join(_ROOT, "polycap_amd", "csrc", "hip", "pc_problem.h")]
+                os.path.join(_ROOT, "polycap_amd", "csrc", "hip", "pc_problem.h"),
+                os.path.join(_ROOT, "polycap_amd", "csrc", "hip", "pc_leak.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
                                    "-ffp-contract=off", "-mfma",   # same IEEE operation sequence as the gfx950 build (fma only where written)
@@ -30,6 +31,13 @@ def lib():
                                         C.POINTER(C.c_int32), c_double_p, c_double_p, c_double_p, c_double_p,
                                         c_int64_p, c_double_p, c_int64_p]
         L.emul_launch_batch.restype = C.c_int
+        L.emul_launch_leak.argtypes = [C.POINTER(ProblemS), C.c_int, C.c_int64, c_double_p, c_double_p, c_double_p, C.c_int, C.c_int64,
+                                       C.POINTER(C.c_int32), c_double_p, c_double_p, c_double_p, c_double_p,
+                                       c_int64_p, c_double_p, c_double_p, c_int64_p, C.POINTER(C.c_int32)]
+        L.emul_launch_leak.restype = C.c_int
+        L.emul_transmission_leak.argtypes = [C.POINTER(ProblemS), C.c_uint64, C.c_int64, C.c_int64, C.c_uint32, C.c_int, C.c_int64,
+                                             c_double_p, c_int64_p, c_double_p, c_double_p, c_int64_p, C.POINTER(C.c_int32)]
+        L.emul_transmission_leak.restype = C.c_int
         L.emul_sample.argtypes = [C.POINTER(ProblemS), C.c_uint64, C.c_int64, c_int64_p, C.POINTER(C.c_uint32), c_double_p]
         L.emul_sample.restype = C.c_int
         _LIB = L
@@ -65,3 +73,63 @@ def sample(problem, seed, slots, attempts):
     if r:
         raise RuntimeError("emul_sample failed: %d" % r)
     return out
+
+
+def sort_leak_records(rec):
+    """Records [n, 14 + nE] (slot, attempt, seq, kind, ...) -> (ext, int) in the reference's list order: per slot the
+    events of the transmitted attempt (the last one) first, then those of earlier attempts in attempt order; attempts
+    that appended a VOID record (kind -1) are dropped, as are the events of an attempt later than the slot's last."""
+    if rec.shape[0] == 0:
+        return rec[:0], rec[:0]
+    void = {(r[0], r[1]) for r in rec if r[3] < 0}
+    keep = np.array([(r[0], r[1]) not in void and r[3] >= 0 for r in rec], dtype=bool)
+    rec = rec[keep]
+    if rec.shape[0] == 0:
+        return rec, rec
+    order = np.lexsort((rec[:, 2], rec[:, 1], rec[:, 0]))
+    rec = rec[order]
+    return rec[rec[:, 3] == 0], rec[rec[:, 3] == 1]
+
+
+def launch_leak(problem, start, direction, elecv, literal=False, max_depth=1024, capacity=None):
+    st = np.ascontiguousarray(start, dtype=np.float64).reshape(-1, 3)
+    di = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+    ev = np.ascontiguousarray(elecv, dtype=np.float64).reshape(-1, 3)
+    n = st.shape[0]
+    ne = problem.n_energies
+    capacity = capacity or max(4096, 64 * n)
+    rc = np.zeros(n, dtype=np.int32)
+    w = np.zeros((n, ne))
+    ec, ed, ee = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 3))
+    ir = np.zeros(n, dtype=np.int64)
+    dt = np.zeros(n)
+    rec = np.zeros((capacity, 14 + ne))
+    nrec = C.c_int64(0)
+    ovf = C.c_int32(0)
+    r = lib().emul_launch_leak(C.byref(problem.s), int(literal), n, dptr(st), dptr(di), dptr(ev), max_depth, capacity,
+                               rc.ctypes.data_as(C.POINTER(C.c_int32)), dptr(w), dptr(ec), dptr(ed), dptr(ee),
+                               ir.ctypes.data_as(c_int64_p), dptr(dt), dptr(rec), C.byref(nrec), C.byref(ovf))
+    if r:
+        raise RuntimeError("emul_launch_leak failed: %d" % r)
+    if nrec.value > capacity:
+        raise RuntimeError("leak record buffer too small: %d > %d" % (nrec.value, capacity))
+    return dict(rc=rc, weights=w, exit_coords=ec, exit_dir=ed, exit_elecv=ee, i_refl=ir, d_travel=dt,
+                records=rec[:nrec.value].copy(), stack_overflow=bool(ovf.value))
+
+
+def transmission_leak(problem, seed, slot0, n_slots, max_attempts=1 << 20, max_depth=1024, capacity=None):
+    ne = problem.n_energies
+    capacity = capacity or max(4096, 64 * n_slots)
+    sw = np.zeros(ne)
+    cnt = np.zeros(4, dtype=np.int64)
+    ew = np.zeros((n_slots, ne))
+    rec = np.zeros((capacity, 14 + ne))
+    nrec = C.c_int64(0)
+    ovf = C.c_int32(0)
+    r = lib().emul_transmission_leak(C.byref(problem.s), seed, slot0, n_slots, max_attempts, max_depth, capacity, dptr(sw),
+                                     cnt.ctypes.data_as(c_int64_p), dptr(ew), dptr(rec), C.byref(nrec), C.byref(ovf))
+    if r:
+        raise RuntimeError("emul_transmission_leak failed: %d" % r)
+    if nrec.value > capacity:
+        raise RuntimeError("leak record buffer too small: %d > %d" % (nrec.value, capacity))
+    return dict(sum_weights=sw, counters=cnt, exit_weights=ew, records=rec[:nrec.value].copy(), stack_overflow=bool(ovf.value))

@@ -1,0 +1,157 @@
+"""GPU parity of the leak ("halo") path, leak_calc=true: pc_hip_launch_photons_leak / pc_hip_transmission_run_leak
+against the CPU oracle (pinned to the reference's tests/leaks.c) and against the host compile of the same device
+headers (bit-identical, including the order of the leak events)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+from tests.test_oracle_leak_known_answers import constants
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import polycap_amd
+    assert polycap_amd.device_count() >= 1, "no HIP device visible"
+    return polycap_amd
+
+
+@pytest.fixture(scope="module")
+def leaks():
+    with open(os.path.join(GOLDEN, "reference_leak_known_answers.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def optic(oracle, known):
+    t = known["test_optic"]
+    return oracle.Optic.from_shape(t["type"], t["length"], t["rad_ext_upstream"], t["rad_ext_downstream"],
+                                   t["rad_int_upstream"], t["rad_int_downstream"], t["focal_dist_upstream"],
+                                   t["focal_dist_downstream"], t["sig_rough"], t["n_cap"], known["glass"]["density"])
+
+
+def problem(pa, optic, energies, amu, scatf, source=(2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.5)):
+    return pa.Problem(optic.z, optic.cap, optic.ext, optic.sig_rough, optic.n_cap, optic.density, energies, amu, scatf, *source)
+
+
+def test_reference_known_answers_through_the_kernel(pa, oracle, optic, leaks):
+    """tests/leaks.c:865-1260 (polycap_photon_launch with leak_calc=true): return codes, event counts, coordinates,
+    directions and weights of the reference, reproduced by the HIP kernel."""
+    t = leaks["photon_leak"]
+    for c in t["cases"]:
+        if c.get("must_not_crash"):
+            E = [float(e) for e in c["energies"]]
+            cs = [constants(leaks, e) for e in E]
+            with pa.TraceContext(problem(pa, optic, E, [a for a, _ in cs], [s for _, s in cs])) as ctx:
+                r = ctx.launch_photons([c["start"]], [c["dir"]], [c["elecv"]], leak_calc=True)
+            assert r["rc"][0] in (1, 0, 2, -1, -2)
+            continue
+        amu, scatf = constants(leaks, c["energy"])
+        with pa.TraceContext(problem(pa, optic, [float(c["energy"])], [amu], [scatf])) as ctx:
+            r = ctx.launch_photons([c["start"]], [c["dir"]], [c["elecv"]], leak_calc=True)
+            ext, intl = ctx.leaks()
+        assert r["rc"][0] == c["rc"], c
+        if "n_ext" in c:
+            assert (len(ext), len(intl)) == (c["n_ext"], c["n_int"]), c
+        for got, exp in ((ext, c.get("ext", [])), (intl, c.get("int", []))):
+            for g, e in zip(got, exp):
+                # long chaotic trajectories (41 reflections in the 6-event case) amplify rounding differences: 2e-5
+                assert np.abs(g[2:5] - np.array(e["coords"])).max() < 2e-5
+                assert np.abs(g[5:8] - np.array(e["dir"])).max() < 2e-5
+                if "w" in e:
+                    assert abs(g[12] - e["w"]) < (t["tol"] if c["energy"] != 10 else 5e-6)
+        if "weight" in c:
+            assert abs(r["weights"][0, 0] - c["weight"]) < t["tol"]
+        if "i_refl" in c:
+            assert r["i_refl"][0] == c["i_refl"] and abs(r["d_travel"][0] - c["d_travel"]) < c["d_travel_tol"]
+
+
+def test_gpu_bit_identical_to_host_compile_with_leaks(pa, oracle, optic, leaks):
+    """Same device headers compiled for the host (tests/emul): identical return codes, weights and leak events, event
+    for event; geometry bit for bit, leak weights to the last bits (they contain exp(-d*amu), and the device's exp is
+    not glibc's), for sampled photons of a divergent source at three energies."""
+    from tests.emul import pyemul
+    E = [10.0, 20.0, 40.0]
+    cs = [constants(leaks, e) for e in E]
+    src = (0.05, 0.1, 0.1, 0.01, 0.01, 0., 0., 0.5)     # 10 mrad divergence: reflections and wall crossings mix
+    prob = problem(pa, optic, E, [a for a, _ in cs], [s for _, s in cs], source=src)
+    ph = oracle.sample_photons(optic, oracle.make_source(*src), 31337, np.arange(500))
+    with pa.TraceContext(prob) as ctx:
+        g = ctx.launch_photons(ph[:, 0:3], ph[:, 3:6], ph[:, 6:9], leak_calc=True)
+        gext, gint = ctx.leaks()
+    e = pyemul.launch_leak(prob, ph[:, 0:3], ph[:, 3:6], ph[:, 6:9])
+    eext, eint = pyemul.sort_leak_records(e["records"])
+    for k in ("rc", "weights", "exit_coords", "exit_dir", "i_refl", "d_travel"):
+        assert np.array_equal(g[k], e[k], equal_nan=True), k
+    assert len(gext) + len(gint) > 100
+    # emulation records: slot, attempt, seq, kind, payload; kernel events: slot, attempt, payload
+    for got, exp in ((gext, eext), (gint, eint)):
+        assert got.shape[0] == exp.shape[0] and np.array_equal(got[:, 0], exp[:, 0])
+        assert np.array_equal(got[:, 2:12], exp[:, 4:14])                                  # coords, direction, elecv, n_refl
+        assert np.allclose(got[:, 12:], exp[:, 14:], rtol=1e-13, atol=0.)
+
+
+def test_explicit_photons_with_leaks_vs_oracle(pa, oracle, optic, leaks):
+    """Identical photons through the oracle and the kernel at 40 keV (many wall crossings): the discrete outcome of the
+    launched photon is unchanged by leak_calc except for the reference's own rejections (launch -1), and the leak
+    events agree one by one wherever the chaotic trajectory has not yet amplified rounding differences."""
+    amu, scatf = constants(leaks, 40)
+    src = (0.05, 0.1, 0.1, 0.01, 0.01, 0., 0., 0.5)     # 10 mrad divergence: reflections and wall crossings mix
+    prob = problem(pa, optic, [40.0], [amu], [scatf], source=src)
+    n = 400
+    ph = oracle.sample_photons(optic, oracle.make_source(*src), 99, np.arange(n))
+    with pa.TraceContext(prob) as ctx:
+        g = ctx.launch_photons(ph[:, 0:3], ph[:, 3:6], ph[:, 6:9], leak_calc=True)
+        gext, gint = ctx.leaks()
+    same_events = total = 0
+    for j in range(n):
+        o = oracle.launch_one_leak(optic, [40.0], [amu], [scatf], ph[j, 0:3], ph[j, 3:6], ph[j, 6:9])
+        assert o["rc"] == g["rc"][j] or o["i_refl"] > 3, j
+        ge, gi = gext[gext[:, 0] == j], gint[gint[:, 0] == j]
+        total += 1
+        if len(ge) == len(o["ext"]) and len(gi) == len(o["int"]):
+            same_events += 1
+            # "short": neither the launched photon nor any leaked fraction has reflected more than a few times
+            nrefl = np.concatenate([o["ext"][:, 9], o["int"][:, 9], [0.]])
+            short = o["i_refl"] <= 3 and nrefl.max() <= 4
+            if short and len(ge):
+                assert np.abs(ge[:, 2:] - o["ext"]).max() < 1e-6
+            if short and len(gi):
+                assert np.abs(gi[:, 2:] - o["int"]).max() < 1e-6
+    assert same_events / total > 0.9
+    assert len(gext) > 50 and len(gint) > 5
+
+
+def test_driver_with_leaks_vs_oracle(pa, oracle, optic, leaks):
+    """polycap_source_get_transmission_efficiencies(leak_calc=true): every slot delivers an exit photon; efficiency and
+    the per-slot leak statistics agree with the oracle on the same seeds within the reference's own chaotic noise;
+    the totals are those of a run without leak_calc up to the photons the leak path rejects; results do not depend on
+    how the slots are split into runs."""
+    t = leaks["source_leak"]
+    amu, scatf = constants(leaks, 10)
+    prob = problem(pa, optic, [10.0], [amu], [scatf], source=tuple(t["source"]))
+    n = 600
+    with pa.TraceContext(prob) as ctx:
+        g = ctx.transmission(20000, 0, n, keep_images=True, leak_calc=True)
+        g0 = ctx.transmission(20000, 0, n, keep_images=True, leak_calc=False)
+        parts = [ctx.transmission(20000, s0, c, leak_calc=True) for s0, c in ((0, 251), (251, n - 251))]
+        ctx.set_option("leak_capacity", 64)           # far too small: the run repeats itself with what it needs
+        small = ctx.transmission(20000, 0, n, leak_calc=True)
+    o = oracle.transmission(optic, oracle.make_source(*t["source"]), [10.0], [amu], [scatf], 20000, 0, n, leak_calc=True)
+    assert g["i_exit"] == n and g["failed_slots"] == 0
+    assert abs(g["efficiencies"][0] - t["efficiencies"][2]) <= t["tol"]
+    assert abs(g["efficiencies"][0] - o["efficiencies"][0]) <= 4. / np.sqrt(n) * o["efficiencies"][0] + 1e-12
+    assert abs(g["efficiencies"][0] - g0["efficiencies"][0]) <= 0.05
+    for kind in ("ext", "int"):
+        assert len(g[kind]) > 0
+        assert abs(len(g[kind]) - len(o[kind])) <= 0.15 * len(o[kind]) + 10
+        assert np.all(np.diff(g[kind][:, 0]) >= 0)                                  # slot-major order
+        assert abs(g[kind][:, 12].sum() - o[kind][:, 12].sum()) <= 0.2 * o[kind][:, 12].sum() + 0.05
+        # partition invariance and buffer growth: identical events, bit for bit
+        both = np.concatenate([p[kind] for p in parts])
+        assert np.array_equal(both, g[kind]) and np.array_equal(small[kind], g[kind])
+    assert np.array_equal(g["counters"][:4], parts[0]["counters"][:4] + parts[1]["counters"][:4])
