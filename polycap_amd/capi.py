@@ -20,6 +20,12 @@ class _Vec3(C.Structure):
     _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
 
 
+class _Leak(C.Structure):
+    """polycap_leak (include/polycap.h)"""
+    _fields_ = [("coords", _Vec3), ("direction", _Vec3), ("elecv", _Vec3), ("n_energies", C.c_size_t),
+                ("weight", C.POINTER(C.c_double)), ("n_refl", C.c_int64)]
+
+
 class _Err(C.Structure):
     _fields_ = [("code", C.c_int), ("message", C.c_char_p)]
 
@@ -104,6 +110,11 @@ def _lib():
         "polycap_photon_new": (vp, [vp, _Vec3, _Vec3, _Vec3, epp]),
         "polycap_photon_launch": (C.c_int, [vp, C.c_size_t, _dp, P(_dp), C.c_bool, epp]),
         "polycap_photon_free": (None, [vp]),
+        "polycap_photon_get_extleak_data": (C.c_bool, [vp, P(P(P(_Leak))), P(C.c_int64), epp]),
+        "polycap_photon_get_intleak_data": (C.c_bool, [vp, P(P(P(_Leak))), P(C.c_int64), epp]),
+        "polycap_transmission_efficiencies_get_extleak_data": (C.c_bool, [vp, P(P(P(_Leak))), P(C.c_int64), epp]),
+        "polycap_transmission_efficiencies_get_intleak_data": (C.c_bool, [vp, P(P(P(_Leak))), P(C.c_int64), epp]),
+        "polycap_leak_free": (None, [P(_Leak)]),
         "polycap_photon_get_dtravel": (C.c_double, [vp]),
         "polycap_photon_get_irefl": (C.c_int64, [vp]),
         "polycap_source_new": (vp, [vp] + [C.c_double] * 8 + [C.c_size_t, _dp, epp]),
@@ -267,7 +278,63 @@ class Description:
         self._h = None
 
 
-class Photon:
+class Leak:
+    """One leak event: where the transmitted fraction of a reflection left the optic (extleak) or reached the exit
+    plane inside the glass (intleak), with the per-energy weights it carried."""
+
+    def __init__(self, coords, direction, elecv, weight, n_refl):
+        self._coords, self._direction, self._elecv, self._weight, self._n_refl = coords, direction, elecv, weight, n_refl
+
+    coords = property(lambda self: self._coords)
+    direction = property(lambda self: self._direction)
+    elecv = property(lambda self: self._elecv)
+    weight = property(lambda self: self._weight)
+    n_refl = property(lambda self: self._n_refl)
+
+
+def _leak_list(getter, handle):
+    """Calls one of the *_get_extleak_data / *_get_intleak_data functions; the C arrays are converted and freed.
+    No events -> the C function's error (ValueError), as with the reference's binding."""
+    L = _lib()
+    arr = C.POINTER(C.POINTER(_Leak))()
+    n = C.c_int64(0)
+    err = _ErrP()
+    getattr(L, getter)(handle, C.byref(arr), C.byref(n), C.byref(err))
+    out = []
+    for k in range(n.value if arr else 0):
+        l = arr[k].contents
+        out.append(Leak(VectorTuple(l.coords.x, l.coords.y, l.coords.z), VectorTuple(l.direction.x, l.direction.y, l.direction.z),
+                        VectorTuple(l.elecv.x, l.elecv.y, l.elecv.z),
+                        np.ctypeslib.as_array(l.weight, shape=(l.n_energies,)).copy(), int(l.n_refl)))
+        L.polycap_leak_free(arr[k])
+    if arr:
+        L.polycap_free(C.cast(arr, C.c_void_p))
+    _check(err)
+    return out
+
+
+class _LeakData:
+    """extleak_data / intleak_data generator properties shared by Photon and TransmissionEfficiencies (cached lists)."""
+    _leak_getters = (None, None)
+
+    def _leaks(self, kind):
+        cache = self.__dict__.setdefault("_leak_cache", {})
+        if kind not in cache:
+            cache[kind] = _leak_list(self._leak_getters[kind], self._h)
+        return cache[kind]
+
+    @property
+    def extleak_data(self):
+        return (l for l in self._leaks(0))
+
+    @property
+    def intleak_data(self):
+        return (l for l in self._leaks(1))
+
+
+class Photon(_LeakData):
+    _leak_getters = ("polycap_photon_get_extleak_data", "polycap_photon_get_intleak_data")
+
     def __init__(self, description, start_coords, start_direction, start_electric_vector, _handle=None):
         L = _lib()
         self._description = description
@@ -286,6 +353,7 @@ class Photon:
         E = np.atleast_1d(np.ascontiguousarray(energies, dtype=np.float64))
         w = _dp()
         err = _ErrP()
+        self.__dict__.pop("_leak_cache", None)
         rc = L.polycap_photon_launch(self._h, E.shape[0], E.ctypes.data_as(_dp), C.byref(w), bool(leak_calc), C.byref(err))
         weights = _take(w, E.shape[0]) if w else None
         _check(err)
@@ -313,7 +381,9 @@ class Photon:
             self._h = None
 
 
-class TransmissionEfficiencies:
+class TransmissionEfficiencies(_LeakData):
+    _leak_getters = ("polycap_transmission_efficiencies_get_extleak_data", "polycap_transmission_efficiencies_get_intleak_data")
+
     def __init__(self, handle, source):
         self._h = handle
         self._source = source   # the C object borrows the source (reference src/polycap-source.c:682)

@@ -896,7 +896,7 @@ int pc_hip_transmission_run_leak(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, 
 	}
 	ctx->leak_seed = seed; ctx->leak_slot0 = slot0; ctx->leak_n_slots = n_slots;
 	ctx->leak_max_attempts = max_attempts; ctx->leak_keep_images = keep_images ? 1 : 0;
-	ctx->leak_capacity_used = ctx->leak_capacity > 0 ? ctx->leak_capacity : std::max<long long>(65536, 8*n_slots);
+	ctx->leak_capacity_used = ctx->leak_capacity > 0 ? ctx->leak_capacity : std::max<long long>(65536, 16*n_slots);
 	int status = pc_transmission_enqueue_leak(ctx);
 	if (status) return status;
 	ctx->run_slots = n_slots;

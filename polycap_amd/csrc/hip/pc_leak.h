@@ -95,6 +95,19 @@ PC_HD void pc_hex_index(double x, double y, double zz, double &q_i, double &r_i)
 	}
 }
 
+/* last node index in [0, upto) whose z does not exceed zval (0 when there is none): what the reference's linear
+ * rescans compute (e.g. src/polycap-capil.c:921-924), by bisection since z is strictly increasing */
+PC_HD int pc_node_find(const pc_tables &T, int upto, double zval)
+{
+	int lo = 0, hi = upto - 1;
+	if (hi < 0 || !(T.z[0] <= zval)) return 0;
+	while (lo < hi) {
+		const int mid = (lo + hi + 1) >> 1;
+		if (T.z[mid] <= zval) lo = mid; else hi = mid - 1;
+	}
+	return lo;
+}
+
 /* last node index below `upto` whose z does not exceed zval, moving from a previous answer (the reference rescans
  * all nodes, src/polycap-capil.c:1023-1026; z is strictly increasing, so the answers agree) */
 PC_HD int pc_node_follow(const pc_tables &T, int upto, int z_id, double zval)
@@ -114,7 +127,7 @@ PC_HD int pc_outer_intersect(const pc_tables &T, const pc_params &Pm, double cx,
 	if (dz == 0.) return 0;
 	double bx = -1.*dx, by = -1.*dy, bz = -1.*dz;
 	pc_norm3(bx, by, bz);
-	int z_id = pc_last_node_le(T, nmax, cz);
+	int z_id = pc_node_find(T, nmax, cz);
 	double cur_ext = (T.ext[z_id+1]-T.ext[z_id])/(T.z[z_id+1]-T.z[z_id]) * (cz - T.z[z_id]) + T.ext[z_id];
 	/* polycap_photon_within_pc_boundary: 1 inside, 0 outside, -1 for a non-positive radius */
 	const int here = (cur_ext <= 0.) ? -1 : (pc_outside_hex(cur_ext, cx, cy) ? 0 : 1);
@@ -184,136 +197,48 @@ PC_HD int pc_outer_intersect(const pc_tables &T, const pc_params &Pm, double cx,
 	return 1;
 }
 
-/* ------------------------------------------------------------------ src/polycap-capil.c:893-1194
- * From the last interaction point ph.P along ph.d through the glass.  1: enters capillary (q, r) after d_travel;
- * 2: reaches the exit plane inside the glass; 3: leaves the optic through its side; <= 0: nothing to trace. */
-template <int NE>
-PC_HD int pc_trace_wall(const pc_tables &T, const pc_params &Pm, const pc_photon<NE> &ph,
-                        double &d_travel, double &q_out, double &r_out)
-{
-	const int nmax = Pm.nmax;
-	const double zend = T.z[nmax], ext_end = T.ext[nmax], ns = Pm.n_shells;
-	const double Px = ph.Px, Py = ph.Py, Pz = ph.Pz, dx = ph.dx, dy = ph.dy, dz = ph.dz;
-	d_travel = 0.; q_out = 0.; r_out = 0.;
-	if (Pz >= zend) return -2;
-	int z_id = pc_last_node_le(T, nmax, Pz);
-	double cur_ext;
-	if (T.z[z_id] != Pz)
-		cur_ext = ((T.ext[z_id+1] - T.ext[z_id])/(T.z[z_id+1] - T.z[z_id])) * (Pz - T.z[z_id]) + T.ext[z_id];
-	else
-		cur_ext = T.ext[z_id];
-	if (Pm.mono) {
-		if (sqrt(Px*Px + Py*Py) > cur_ext) return -2;
-	} else {
-		if (pc_outside_hex(cur_ext, Px, Py)) return -2;
-	}
-	double q_i, r_i, q_new = 0., r_new = 0.;
-	pc_hex_index(Px, Py, cur_ext/Pm.hexscale, q_i, r_i);
+/* ==================================================================== the lane state machine
+ *
+ * A launch is cut into units of work so that the lanes of a wave can be scheduled by kind of work (pc_leak_kernels.h):
+ * every unit advances one lane by one march step, one segment visit, one block/step of the wall search, one segment
+ * probe of the neighbouring capillary, or one of the short bookkeeping steps.  Run one after the other on a single lane
+ * (pc_leak_launch below, which the host compile of the tests uses) the units are exactly the sequential algorithm.
+ */
+enum {
+	PC_LS_MARCH = 0,       /* certified march between interactions (pc_march_step) */
+	PC_LS_EVENT,           /* literal visit of one segment (pc_event_pre) */
+	PC_LS_REFLECT,         /* a wall hit is due: geometry of the reflection, start of the wall search */
+	PC_LS_WALL_STEP,       /* wall search: cap/10 stepping through the glass (src/polycap-capil.c:1016-1064) */
+	PC_LS_WALL_PROBE,      /* wall search: segments of the neighbouring capillary (:1105-1128) */
+	PC_LS_REFLECT_END,     /* weights, leak events, child photon or mirror reflection (:625-887, :1345-1355) */
+	PC_LS_INWALL_END,      /* launch inside the glass: what the wall search found (src/polycap-photon.c:698-870) */
+	PC_LS_ENDED,           /* the photon being traced has ended: pop a suspended parent or finish the launch */
+	PC_LS_DONE             /* launch finished, rc holds polycap_photon_launch's return code */
+};
 
-	pc_photon<NE> probe = ph;      /* same ray, other capillary axes */
-	int iesc = 0;
-	double p0x, p0y, hx = Px, hy = Py, hz = Pz, nx, ny, nz;
-	double px = Px, py = Py, pz = Pz;
+struct pc_wall {
+	int z_id, seg_step, seg_slope, cool, iesc, wt;
+	long long nst;
+	double q_i, r_i, q_new, r_new;
+	double px, py, pz;                 /* point reached by the stepping */
+	double dist, base, step;           /* dist = base + nst*step */
+	double ext_slope, cap_slope, seg_z, seg_ext, seg_cap;
+	double hx, hy, hz;                 /* intersection with the neighbouring capillary */
+	double d_travel, q_out, r_out;     /* results */
+};
 
-	if (Pm.mono) {
-		/* :991-1011 */
-		probe.kx = 0.; probe.ky = 0.;
-		do {
-			iesc = pc_segment(T, probe, z_id, p0x, p0y, hx, hy, hz, nx, ny, nz);
-			z_id++;
-		} while (iesc != 1 && z_id < nmax-1);
-	} else {
-		double dist = 0.;
-		for (;;) {
-			/* :1016-1064 cap/10 steps until the hexagon cell changes */
-			do {
-				dist += T.cap[z_id]/10.;
-				px = Px + dist*dx;
-				py = Py + dist*dy;
-				pz = Pz + dist*dz;
-				z_id = pc_node_follow(T, nmax, z_id, pz);
-				const double idzs = (T.z[z_id+1] - T.z[z_id]);
-				cur_ext = ((T.ext[z_id+1] - T.ext[z_id])/idzs) * (pz - T.z[z_id]) + T.ext[z_id];
-				const double rad0 = ((T.cap[z_id+1] - T.cap[z_id])/idzs) * (pz - T.z[z_id]) + T.cap[z_id];
-				const double zz = cur_ext/Pm.hexscale;
-				pc_hex_index(px, py, zz, q_new, r_new);
-				/* :1043-1063 the ray found the capillary (q_i, r_i) it started next to */
-				const double ccy = r_i * (3./2) * zz;
-				const double ccx = (2.* q_i+r_i) * PC_COSPI_6 * zz;
-				const double d_phot0 = sqrt((px-ccx)*(px-ccx)+(py-ccy)*(py-ccy));
-				if (d_phot0 < rad0 && fabs(q_i) <= ns && fabs(r_i) <= ns && fabs(-1.*q_i-r_i) <= ns) {
-					const double rx = px - Px, ry = py - Py, rz = pz - Pz;
-					const double dt = sqrt(rx*rx + ry*ry + rz*rz);
-					if (dt > 1.e-5) {
-						d_travel = dt; r_out = r_i; q_out = q_i;
-						return 1;
-					}
-				}
-			} while (q_new == q_i && r_new == r_i && pz <= zend);
-
-			/* :1068-1100 outside the hexagon stacking, or beyond the exit plane */
-			if (fabs(q_new) > ns || fabs(r_new) > ns || fabs(-1.*q_new-r_new) > ns || pz > zend) {
-				const double tx = Px + dx * (zend-Pz)/dz;
-				const double ty = Py + dy * (zend-Pz)/dz;
-				r_out = r_new; q_out = q_new;
-				double rx = px - Px, ry = py - Py, rz = pz - Pz;
-				if (pc_outside_hex(ext_end, tx, ty)) {
-					double ix_, iy_, iz_;
-					if (pc_outer_intersect(T, Pm, tx, ty, zend, dx, dy, dz, ix_, iy_, iz_)) {
-						rx = ix_ - Px; ry = iy_ - Py; rz = iz_ - Pz;
-					}
-					d_travel = sqrt(rx*rx + ry*ry + rz*rz);
-					return 3;
-				}
-				d_travel = sqrt(rx*rx + ry*ry + rz*rz);
-				return 2;
-			}
-
-			/* :1105-1128 wall of capillary (q_new, r_new), segment by segment */
-			probe.ky = r_new * (3./2);
-			probe.kx = (2.* q_new+r_new) * PC_COSPI_6;
-			iesc = 0;
-			hx = Px; hy = Py; hz = Pz;
-			do {
-				iesc = pc_segment(T, probe, z_id, p0x, p0y, hx, hy, hz, nx, ny, nz);
-				z_id++;
-			} while (iesc != 1 && z_id < nmax-1);
-			if (z_id >= nmax && iesc != 0) {
-				/* :1129-1135 */
-				q_i = q_new;
-				r_i = r_new;
-				z_id = nmax-1;
-				continue;
-			}
-			break;
-		}
-	}
-
-	/* :1142-1190 */
-	r_out = r_new; q_out = q_new;
-	if (iesc != 1) {
-		const double tx = Px + dx * (zend-Pz)/dz;
-		const double ty = Py + dy * (zend-Pz)/dz;
-		double rx = tx - Px, ry = ty - Py, rz = zend - Pz;
-		if (pc_outside_hex(ext_end, tx, ty)) {
-			double ix_, iy_, iz_;
-			if (pc_outer_intersect(T, Pm, tx, ty, zend, dx, dy, dz, ix_, iy_, iz_)) {
-				rx = ix_ - Px; ry = iy_ - Py; rz = iz_ - Pz;
-			}
-			d_travel = sqrt(rx*rx + ry*ry + rz*rz);
-			return 3;
-		}
-		d_travel = sqrt(rx*rx + ry*ry + rz*rz);
-		return 2;
-	}
-	{
-		const double rx = hx - Px, ry = hy - Py, rz = hz - Pz;
-		d_travel = sqrt(rx*rx + ry*ry + rz*rz);
-	}
-	return (z_id >= nmax) ? 2 : 1;
-}
-
-/* ------------------------------------------------------------------ the depth-first run of one launched photon */
+struct pc_leak_lane {
+	pc_photon<0> ph;
+	pc_hit h;
+	pc_refl_geom g;
+	pc_wall w;
+	pc_leak_ctx cx;
+	double *wts;                       /* weights of the photon being traced (in its stack frame) */
+	double z0, sdx, sdy, sdz;
+	int st, rc;
+	int lvl, calls, entrance, have_final, how, geom_ok;
+	int after_wall;                    /* state that takes over when the wall search is finished */
+};
 
 /* how the photon being traced came to an end, in polycap_capil_trace's return codes */
 enum { PC_END_ABSORBED = 0, PC_END_CALLS = 1, PC_END_ERROR = -1, PC_END_EXIT = -2 };
@@ -360,164 +285,383 @@ PC_HD void pc_set_boundary_flag(const pc_params &Pm, pc_photon<NE> &ph)
 	}
 }
 
-/* Runs the launched photon and everything that leaks out of it.  `ph` comes from pc_launch_init (st0 = its return
- * value); weights live in frame 0 of cx.frames.  z0 = start_coords.z.  Returns polycap_photon_launch's return code. */
-PC_HD int pc_leak_launch(const pc_tables &T, const pc_params &Pm, pc_leak_ctx &cx, pc_photon<0> &ph, int st0, double z0)
-{
-	const int ne = cx.ne, nmax = Pm.nmax;
-	const long fstride = PC_LF_HDR + ne;
-	int lvl = 0;                       /* frame of the photon being traced; frames below it hold its suspended ancestors */
-	double *w = cx.frames + PC_LF_HDR;  /* its weights */
-	for (int e = 0; e < ne; e++) w[e] = 1.;
-	ph.wmem = w; ph.wstride = 1; ph.wset = 1;
-	cx.seq = 0;
-	int calls = nmax + 1;              /* polycap_capil_trace calls left in the loop that drives this photon */
-	int st = st0;
-	int entrance = 0;                  /* the reflection in progress is the one off the entrance face (return code ignored) */
-	int pending = 0;                   /* 1: a reflection at hit h is due for the current photon */
-	pc_hit h;
-	h.nx = h.ny = h.nz = h.cosalfa = 0.; h.ix = 0;
-	int have_final = 0;               /* 1: entrance reflection (launch returns 2); 2, 3: launched inside the glass */
 
-	const double sdx = ph.dx, sdy = ph.dy, sdz = ph.dz;       /* normalised start direction */
-	if (st0 == PC_ST_DONE) {
-		if (ph.rc != 2) return ph.rc;                        /* -2: missed the optic */
-		pc_trace_begin(ph);                                  /* ray constants for the wall search */
-		if (z0 == 0.) {
-			/* src/polycap-photon.c:647-672: reflection off the entrance face, normal = optic axis */
-			h.nx = 0.; h.ny = 0.; h.nz = 1.; h.cosalfa = ph.dz; h.ix = 0;
-			entrance = 1; pending = 1;
-			have_final = 1;
-		} else {
-			/* :674-870 launched inside the glass */
-			double dtr, qn, rn;
-			const int wt = pc_trace_wall(T, Pm, ph, dtr, qn, rn);
-			if (wt <= 0) { ph.rc = -1; return -1; }
-			for (int e = 0; e < ne; e++) w[e] = w[e] * exp(-1.*dtr*cx.amu[e]);
-			const double f = dtr / sqrt(ph.dx*ph.dx + ph.dy*ph.dy + ph.dz*ph.dz);
-			ph.Px = ph.Px + f*ph.dx; ph.Py = ph.Py + f*ph.dy; ph.Pz = ph.Pz + f*ph.dz;
-			if (wt == 3) pc_leak_emit(cx, PC_LEAK_EXT, ph.Px, ph.Py, ph.Pz, ph.dx, ph.dy, ph.dz, ph.ex, ph.ey, ph.ez, ph.irefl, w);
-			if (wt == 2) pc_leak_emit(cx, PC_LEAK_INT, ph.Px, ph.Py, ph.Pz, ph.dx, ph.dy, ph.dz, ph.ex, ph.ey, ph.ez, ph.irefl, w);
-			have_final = 2;      /* the launched photon itself ends as a leak event and is reported absorbed (:808-870) */
-			if (wt == 1) {
-				ph.dtravel = ph.dtravel + dtr;
-				ph.ky = rn * (3./2);
-				ph.kx = (2.*qn + rn) * PC_COSPI_6;
-				ph.kn = sqrt(ph.kx*ph.kx + ph.ky*ph.ky);
-				pc_set_boundary_flag(Pm, ph);
-				ph.i = pc_last_node_le(T, nmax + 1, ph.Pz);
-				ph.rc = 0;
-				pc_trace_begin(ph);
-				st = PC_ST_MARCH;
-			} else {
-				calls = 0;       /* nothing to trace: straight to the common tail below */
-				have_final = 3;
+/* ---- wall search, src/polycap-capil.c:893-1194: from ph.P along ph.d through the glass.
+ * Result in L.w.wt: 1 enters capillary (q_out, r_out) after d_travel; 2 reaches the exit plane inside the glass; 3 leaves
+ * the optic through its side; <= 0 nothing to trace. */
+
+/* end of the search without an intersection (:1068-1100 with the stepped point, :1147-1172 with the exit-plane point) */
+PC_HD void pc_wall_to_exit(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L, int stepped)
+{
+	pc_wall &W = L.w;
+	const pc_photon<0> &ph = L.ph;
+	const int nmax = Pm.nmax;
+	const double zend = T.z[nmax], ext_end = T.ext[nmax];
+	const double tx = ph.Px + ph.dx * (zend-ph.Pz)/ph.dz;
+	const double ty = ph.Py + ph.dy * (zend-ph.Pz)/ph.dz;
+	W.r_out = W.r_new; W.q_out = W.q_new;
+	double rx, ry, rz;
+	if (stepped) { rx = W.px - ph.Px; ry = W.py - ph.Py; rz = W.pz - ph.Pz; }
+	else { rx = tx - ph.Px; ry = ty - ph.Py; rz = zend - ph.Pz; }
+	if (pc_outside_hex(ext_end, tx, ty)) {
+		double ix_, iy_, iz_;
+		if (pc_outer_intersect(T, Pm, tx, ty, zend, ph.dx, ph.dy, ph.dz, ix_, iy_, iz_)) {
+			rx = ix_ - ph.Px; ry = iy_ - ph.Py; rz = iz_ - ph.Pz;
+		}
+		W.wt = 3;
+	} else {
+		W.wt = 2;
+	}
+	W.d_travel = sqrt(rx*rx + ry*ry + rz*rz);
+}
+
+/* :918-971.  Returns the next state: WALL_STEP / WALL_PROBE, or `after` with W.wt <= 0 when there is nothing to trace */
+PC_HD int pc_wall_begin(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L, int after)
+{
+	pc_wall &W = L.w;
+	const pc_photon<0> &ph = L.ph;
+	const int nmax = Pm.nmax;
+	L.after_wall = after;
+	W.d_travel = 0.; W.q_out = 0.; W.r_out = 0.; W.q_new = 0.; W.r_new = 0.;
+	W.wt = -2;
+	if (ph.Pz >= T.z[nmax]) return after;
+	int z_id = pc_node_find(T, nmax, ph.Pz);
+	double cur_ext;
+	if (T.z[z_id] != ph.Pz)
+		cur_ext = ((T.ext[z_id+1] - T.ext[z_id])/(T.z[z_id+1] - T.z[z_id])) * (ph.Pz - T.z[z_id]) + T.ext[z_id];
+	else
+		cur_ext = T.ext[z_id];
+	if (Pm.mono) {
+		if (sqrt(ph.Px*ph.Px + ph.Py*ph.Py) > cur_ext) return after;
+	} else {
+		if (pc_outside_hex(cur_ext, ph.Px, ph.Py)) return after;
+	}
+	pc_hex_index(ph.Px, ph.Py, cur_ext/Pm.hexscale, W.q_i, W.r_i);
+	W.z_id = z_id;
+	W.px = ph.Px; W.py = ph.Py; W.pz = ph.Pz;
+	W.hx = ph.Px; W.hy = ph.Py; W.hz = ph.Pz;
+	W.dist = 0.; W.base = 0.; W.nst = 0; W.step = 0.;
+	W.seg_step = -1; W.seg_slope = -1; W.cool = 0;
+	W.iesc = 0;
+	return Pm.mono ? PC_LS_WALL_PROBE : PC_LS_WALL_STEP;
+}
+
+/* one unit of the stepping loop (:1016-1064): either one certified block of steps, or one literal step with its tests */
+PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L, int after)
+{
+	pc_wall &W = L.w;
+	const pc_photon<0> &ph = L.ph;
+	const int nmax = Pm.nmax;
+	const double zend = T.z[nmax], ns = Pm.n_shells;
+	const double Px = ph.Px, Py = ph.Py, Pz = ph.Pz, dx = ph.dx, dy = ph.dy, dz = ph.dz;
+	int z_id = W.z_id;
+
+	/* ---- certified skipping.  Inside one profile segment the point relative to the centre of cell (q_i, r_i),
+	 * u = p - K*zz(z), moves on a straight line while the cell hexagon (inradius zz*sqrt(3)/2) and the capillary circle
+	 * (radius rad0) change linearly.  |n.u| - h is convex along the block, so the hexagon tests hold inside the block if
+	 * they hold at both ends; the circle test holds if the closest approach of the line to the centre stays outside the
+	 * larger of the two end radii.  With a margin far above rounding (1e-6 of the cell size) none of the next m literal
+	 * steps can leave the loop, so only their effect on `dist` is carried out. */
+	if (!Pm.literal && W.cool == 0 && dz > 0. && T.z[z_id] <= W.pz && W.pz < T.z[z_id+1]) {
+		const double stp = T.cap[z_id]/10.;
+		const double room = (T.z[z_id+1] - W.pz)/(stp*dz);
+		int m = (room > 1.e6) ? 1000000 : (int)room - 2;
+		if (m >= 8) {
+			const double es = (T.ext[z_id+1] - T.ext[z_id])/(T.z[z_id+1] - T.z[z_id]);
+			const double cs = (T.cap[z_id+1] - T.cap[z_id])/(T.z[z_id+1] - T.z[z_id]);
+			const int inside_stack = (fabs(W.q_i) <= ns && fabs(W.r_i) <= ns && fabs(-1.*W.q_i-W.r_i) <= ns);
+			const double Kx = (2.*W.q_i + W.r_i) * PC_COSPI_6, Ky = W.r_i * 1.5;
+			const double zz0 = (es * (W.pz - T.z[z_id]) + T.ext[z_id]) / Pm.hexscale;
+			const double dzz = es * dz / Pm.hexscale;                 /* d zz / d dist */
+			const double r00 = cs * (W.pz - T.z[z_id]) + T.cap[z_id];
+			const double u0x = W.px - Kx*zz0, u0y = W.py - Ky*zz0;
+			const double vx = dx - Kx*dzz, vy = dy - Ky*dzz;
+			const double margin = 1.e-6 * zz0;
+			int ok = 0;
+			for (; m >= 8; m >>= 2) {
+				const double D = (double)m * stp * (1. + 1.e-9);
+				const double u1x = u0x + vx*D, u1y = u0y + vy*D;
+				const double h0 = PC_COSPI_6*zz0 - margin, h1 = PC_COSPI_6*(zz0 + dzz*D) - margin;
+				if (fabs(u0x) > h0 || fabs(0.5*u0x + PC_COSPI_6*u0y) > h0 || fabs(0.5*u0x - PC_COSPI_6*u0y) > h0) break;
+				if (fabs(u1x) > h1 || fabs(0.5*u1x + PC_COSPI_6*u1y) > h1 || fabs(0.5*u1x - PC_COSPI_6*u1y) > h1) continue;
+				if (inside_stack) {
+					const double vv = vx*vx + vy*vy;
+					double ts = (vv > 0.) ? -(u0x*vx + u0y*vy)/vv : 0.;
+					ts = (ts < 0.) ? 0. : ((ts > D) ? D : ts);
+					const double cxm = u0x + vx*ts, cym = u0y + vy*ts;
+					const double r1 = r00 + cs*dz*D;
+					const double rmax = ((r00 > r1) ? r00 : r1) + margin;
+					if (cxm*cxm + cym*cym < rmax*rmax) continue;
+				}
+				ok = 1;
+				break;
 			}
+			if (ok) {
+				if (z_id != W.seg_step) { W.seg_step = z_id; W.step = stp; W.base = W.dist; W.nst = 0; }
+				W.nst += m;
+				W.dist = W.base + (double)W.nst*W.step;
+				W.px = Px + W.dist*dx;
+				W.py = Py + W.dist*dy;
+				W.pz = Pz + W.dist*dz;
+				return PC_LS_WALL_STEP;
+			}
+			W.cool = 8;
 		}
 	}
+	if (W.cool > 0) W.cool--;
 
-	for (;;) {
-		int ended = 0, how = 0;
-		if (!pending) {
-			/* ---- fly to the next wall hit: certified march + literal segment visits of pc_device.h */
-			if (calls <= 0) { ended = 1; how = PC_END_CALLS; }
-			while (!ended && !pending) {
-				while (st == PC_ST_MARCH) st = pc_march_step(T, Pm, ph);
-				if (st == PC_ST_EVENT) st = pc_event_pre(T, Pm, ph, h);
-				if (st == PC_ST_REFLECT) { pending = 1; calls--; }
-				else if (st == PC_ST_DONE) { ended = 1; how = (ph.rc == 1) ? PC_END_EXIT : PC_END_ERROR; calls--; }
+	/* ---- one literal step.  dist = base + nst*step: the path length after nst steps of the current size (the reference
+	 * adds the steps one by one; the product differs from that sum by rounding only and lets a block be skipped in O(1)) */
+	if (z_id != W.seg_step) { W.seg_step = z_id; W.step = T.cap[z_id]/10.; W.base = W.dist; W.nst = 0; }
+	W.nst++;
+	W.dist = W.base + (double)W.nst*W.step;
+	const double px = Px + W.dist*dx, py = Py + W.dist*dy, pz = Pz + W.dist*dz;
+	W.px = px; W.py = py; W.pz = pz;
+	z_id = pc_node_follow(T, nmax, z_id, pz);
+	W.z_id = z_id;
+	if (z_id != W.seg_slope) {
+		W.seg_slope = z_id;
+		const double dzs = (T.z[z_id+1] - T.z[z_id]);
+		W.seg_z = T.z[z_id]; W.seg_ext = T.ext[z_id]; W.seg_cap = T.cap[z_id];
+		W.ext_slope = (T.ext[z_id+1] - W.seg_ext)/dzs;
+		W.cap_slope = (T.cap[z_id+1] - W.seg_cap)/dzs;
+	}
+	const double cur_ext = W.ext_slope * (pz - W.seg_z) + W.seg_ext;
+	const double rad0 = W.cap_slope * (pz - W.seg_z) + W.seg_cap;
+	const double zz = cur_ext/Pm.hexscale;
+	pc_hex_index(px, py, zz, W.q_new, W.r_new);
+	/* :1043-1063 the ray found the capillary (q_i, r_i) it started next to */
+	const double ccy = W.r_i * (3./2) * zz;
+	const double ccx = (2.* W.q_i+W.r_i) * PC_COSPI_6 * zz;
+	const double d_phot0 = sqrt((px-ccx)*(px-ccx)+(py-ccy)*(py-ccy));
+	if (d_phot0 < rad0 && fabs(W.q_i) <= ns && fabs(W.r_i) <= ns && fabs(-1.*W.q_i-W.r_i) <= ns) {
+		const double rx = px - Px, ry = py - Py, rz = pz - Pz;
+		const double dt = sqrt(rx*rx + ry*ry + rz*rz);
+		if (dt > 1.e-5) {
+			W.d_travel = dt; W.r_out = W.r_i; W.q_out = W.q_i; W.wt = 1;
+			return after;
+		}
+	}
+	if (W.q_new == W.q_i && W.r_new == W.r_i && pz <= zend)
+		return PC_LS_WALL_STEP;
+
+	/* :1068-1100 outside the hexagon stacking, or beyond the exit plane */
+	if (fabs(W.q_new) > ns || fabs(W.r_new) > ns || fabs(-1.*W.q_new-W.r_new) > ns || pz > zend) {
+		pc_wall_to_exit(T, Pm, L, 1);
+		return after;
+	}
+	/* :1105 on to the wall of capillary (q_new, r_new) */
+	W.iesc = 0;
+	W.hx = Px; W.hy = Py; W.hz = Pz;
+	return PC_LS_WALL_PROBE;
+}
+
+/* one unit of the segment search in the neighbouring capillary (:1107-1128; mono-capillary :991-1011) */
+PC_HD int pc_wall_probe(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L, int after)
+{
+	pc_wall &W = L.w;
+	const int nmax = Pm.nmax;
+	pc_photon<0> probe = L.ph;          /* same ray, other capillary axis */
+	if (Pm.mono) { probe.kx = 0.; probe.ky = 0.; }
+	else { probe.ky = W.r_new * (3./2); probe.kx = (2.* W.q_new+W.r_new) * PC_COSPI_6; }
+	double p0x, p0y, nx, ny, nz;
+	W.iesc = pc_segment(T, probe, W.z_id, p0x, p0y, W.hx, W.hy, W.hz, nx, ny, nz);
+	W.z_id++;
+	if (W.iesc != 1 && W.z_id < nmax-1)
+		return PC_LS_WALL_PROBE;
+	if (!Pm.mono && W.z_id >= nmax && W.iesc != 0) {
+		/* :1129-1135 nothing in this capillary: on to the next hexagon cell */
+		W.q_i = W.q_new;
+		W.r_i = W.r_new;
+		W.z_id = nmax-1;
+		return PC_LS_WALL_STEP;
+	}
+	/* :1142-1190 */
+	W.r_out = W.r_new; W.q_out = W.q_new;
+	if (W.iesc != 1) {
+		pc_wall_to_exit(T, Pm, L, 0);
+		return after;
+	}
+	const double rx = W.hx - L.ph.Px, ry = W.hy - L.ph.Py, rz = W.hz - L.ph.Pz;
+	W.d_travel = sqrt(rx*rx + ry*ry + rz*rz);
+	W.wt = (W.z_id >= nmax) ? 2 : 1;
+	return after;
+}
+
+/* ---- launch ------------------------------------------------------------------------------------------------------ */
+
+/* `L.ph` comes from pc_launch_init (st0 = its return value), z0 = start_coords.z; L.cx is set up by the caller. */
+PC_HD void pc_leak_begin(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L, int st0, double z0)
+{
+	pc_photon<0> &ph = L.ph;
+	const int ne = L.cx.ne;
+	L.lvl = 0;
+	L.wts = L.cx.frames + PC_LF_HDR;
+	for (int e = 0; e < ne; e++) L.wts[e] = 1.;
+	ph.wmem = L.wts; ph.wstride = 1; ph.wset = 1;
+	L.cx.seq = 0;
+	L.calls = Pm.nmax + 1;             /* polycap_capil_trace calls left in the loop that drives this photon */
+	L.entrance = 0; L.have_final = 0; L.how = 0; L.rc = 0;
+	L.z0 = z0;
+	L.sdx = ph.dx; L.sdy = ph.dy; L.sdz = ph.dz;
+	L.h.nx = L.h.ny = L.h.nz = L.h.cosalfa = 0.; L.h.ix = 0;
+	if (st0 != PC_ST_DONE) { L.st = PC_LS_MARCH; return; }
+	if (ph.rc != 2) { L.rc = ph.rc; L.st = PC_LS_DONE; return; }       /* -2: missed the optic */
+	pc_trace_begin(ph);                                                  /* ray constants for the wall search */
+	if (z0 == 0.) {
+		/* src/polycap-photon.c:647-672: reflection off the entrance face, normal = optic axis */
+		L.h.nx = 0.; L.h.ny = 0.; L.h.nz = 1.; L.h.cosalfa = ph.dz; L.h.ix = 0;
+		L.entrance = 1;
+		L.have_final = 1;
+		L.st = PC_LS_REFLECT;
+	} else {
+		/* :674-870 launched inside the glass */
+		L.have_final = 2;
+		L.st = pc_wall_begin(T, Pm, L, PC_LS_INWALL_END);
+	}
+}
+
+/* the short states; MARCH, WALL_STEP and WALL_PROBE units are called directly by the schedulers */
+PC_HD void pc_leak_unit_other(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L)
+{
+	pc_photon<0> &ph = L.ph;
+	pc_leak_ctx &cx = L.cx;
+	const int ne = cx.ne, nmax = Pm.nmax;
+	const long fstride = PC_LF_HDR + ne;
+	switch (L.st) {
+	case PC_LS_EVENT: {
+		const int st = pc_event_pre(T, Pm, ph, L.h);
+		if (st == PC_ST_MARCH) { L.st = PC_LS_MARCH; }
+		else if (st == PC_ST_REFLECT) { L.calls--; L.st = PC_LS_REFLECT; }
+		else { L.calls--; L.how = (ph.rc == 1) ? PC_END_EXIT : PC_END_ERROR; L.st = PC_LS_ENDED; }
+		break;
+	}
+	case PC_LS_REFLECT: {
+		/* src/polycap-capil.c:596-619 */
+		L.geom_ok = pc_reflect_geom(ph, L.h.nx, L.h.ny, L.h.nz, L.g);     /* -1: alfa < 0 */
+		L.w.wt = 0;
+		L.st = (L.geom_ok >= 0) ? pc_wall_begin(T, Pm, L, PC_LS_REFLECT_END) : PC_LS_REFLECT_END;
+		break;
+	}
+	case PC_LS_REFLECT_END: {
+		/* :625-887 */
+		int r = L.geom_ok;
+		int wt = L.w.wt;
+		const double dtr = L.w.d_travel, qn = L.w.q_out, rn = L.w.r_out;
+		if (r >= 0 && wt <= 0) r = -1;
+		int leak_flag = 0, keep = 0;
+		double *w = L.wts, *wl = nullptr;
+		/* the transmitted fractions go straight into the next frame's weight slots: they are the child's weights if one
+		 * is spawned, and scratch otherwise */
+		if (r >= 0 && L.lvl + 1 >= cx.max_depth) { cx.stack_overflow = 1; r = -1; }
+		if (r >= 0) {
+			wl = cx.frames + (long)(L.lvl + 1)*fstride + PC_LF_HDR;
+			for (int e = 0; e < ne; e++) {
+				double rtot, r_rough;
+				if (pc_fresnel(cx.ec[e], L.g, rtot, r_rough) < 0) { r = -1; break; }
+				wl[e] = (1.-rtot * r_rough) * w[e] * exp(-1.*dtr*cx.amu[e]);
+				if (wl[e] >= 1.e-4) leak_flag = 1;
+				w[e] = w[e] * rtot * r_rough;
+				if (w[e] >= 1.e-4) keep = 1;
 			}
 		}
-		if (pending) {
-			/* ---- reflection with leak bookkeeping: src/polycap-capil.c:596-887 */
-			pending = 0;
-			pc_refl_geom g;
-			int r = pc_reflect_geom(ph, h.nx, h.ny, h.nz, g);     /* -1: alfa < 0 */
-			double dtr = 0., qn = 0., rn = 0.;
-			int wt = 0;
-			if (r >= 0) {
-				wt = pc_trace_wall(T, Pm, ph, dtr, qn, rn);
-				if (wt <= 0) r = -1;
-			}
-			int leak_flag = 0, keep = 0;
-			double *wl = nullptr;
-			if (r >= 0) {
-				/* the transmitted fractions go straight into the next frame's weight slots: they are the child's weights
-				 * if one is spawned, and scratch otherwise */
-				if (lvl + 1 >= cx.max_depth) { cx.stack_overflow = 1; r = -1; }
-			}
-			if (r >= 0) {
-				wl = cx.frames + (long)(lvl + 1)*fstride + PC_LF_HDR;
-				for (int e = 0; e < ne; e++) {
-					double rtot, r_rough;
-					if (pc_fresnel(cx.ec[e], g, rtot, r_rough) < 0) { r = -1; break; }
-					wl[e] = (1.-rtot * r_rough) * w[e] * exp(-1.*dtr*cx.amu[e]);
-					if (wl[e] >= 1.e-4) leak_flag = 1;
-					w[e] = w[e] * rtot * r_rough;
-					if (w[e] >= 1.e-4) keep = 1;
+		if (r >= 0) {
+			ph.ex = fabs(ph.ex); ph.ey = fabs(ph.ey); ph.ez = fabs(ph.ez);
+			r = keep;
+			if (leak_flag) {
+				const double f = dtr / sqrt(ph.dx*ph.dx + ph.dy*ph.dy + ph.dz*ph.dz);
+				const double lx = ph.Px + f*ph.dx, ly = ph.Py + f*ph.dy, lz = ph.Pz + f*ph.dz;
+				if (wt == 1) {
+					const int zi = pc_node_find(T, nmax, lz);
+					const double ce = ((T.ext[zi+1] - T.ext[zi])/(T.z[zi+1] - T.z[zi])) * (lz - T.z[zi]) + T.ext[zi];
+					if (Pm.mono) { if (sqrt(lx*lx + ly*ly) >= ce) wt = 3; }
+					else if (ce > 0. && pc_outside_hex(ce, lx, ly)) wt = 3;
 				}
-			}
-			if (r >= 0) {
-				ph.ex = fabs(ph.ex); ph.ey = fabs(ph.ey); ph.ez = fabs(ph.ez);
-				r = keep;
-				if (leak_flag) {
-					const double f = dtr / sqrt(ph.dx*ph.dx + ph.dy*ph.dy + ph.dz*ph.dz);
-					const double lx = ph.Px + f*ph.dx, ly = ph.Py + f*ph.dy, lz = ph.Pz + f*ph.dz;
-					if (wt == 1) {
-						const int zi = pc_last_node_le(T, nmax, lz);
-						const double ce = ((T.ext[zi+1] - T.ext[zi])/(T.z[zi+1] - T.z[zi])) * (lz - T.z[zi]) + T.ext[zi];
-						if (Pm.mono) { if (sqrt(lx*lx + ly*ly) >= ce) wt = 3; }
-						else if (ce > 0. && pc_outside_hex(ce, lx, ly)) wt = 3;
-					}
-					if (wt == 3) pc_leak_emit(cx, PC_LEAK_EXT, lx, ly, lz, ph.dx, ph.dy, ph.dz, ph.ex, ph.ey, ph.ez, ph.irefl, wl);
-					if (wt == 2) pc_leak_emit(cx, PC_LEAK_INT, lx, ly, lz, ph.dx, ph.dy, ph.dz, ph.ex, ph.ey, ph.ez, ph.irefl, wl);
-					if (wt == 1 && lz < T.z[nmax]) {
-						/* :711-803 suspend this photon, go on with the leaked fraction in capillary (qn, rn) */
-						pc_frame_save(cx.frames + (long)lvl*fstride, ph, h, calls, keep, entrance);
-						lvl++;
-						w = wl;
-						ph.wmem = w;
-						ph.Px = lx; ph.Py = ly; ph.Pz = lz;
-						ph.dtravel = ph.dtravel + dtr;
-						if (Pm.mono) { ph.kx = 0.; ph.ky = 0.; }
-						else { ph.ky = (3./2) * rn; ph.kx = (2.*qn + rn) * PC_COSPI_6; }
-						ph.kn = sqrt(ph.kx*ph.kx + ph.ky*ph.ky);
-						pc_set_boundary_flag(Pm, ph);
-						ph.i = pc_last_node_le(T, nmax + 1, lz);
-						calls = nmax + 1 - ph.i;
-						ph.rc = 0;
-						entrance = 0;
-						pc_trace_begin(ph);
-						st = PC_ST_MARCH;
-						continue;
-					}
+				if (wt == 3) pc_leak_emit(cx, PC_LEAK_EXT, lx, ly, lz, ph.dx, ph.dy, ph.dz, ph.ex, ph.ey, ph.ez, ph.irefl, wl);
+				if (wt == 2) pc_leak_emit(cx, PC_LEAK_INT, lx, ly, lz, ph.dx, ph.dy, ph.dz, ph.ex, ph.ey, ph.ez, ph.irefl, wl);
+				if (wt == 1 && lz < T.z[nmax]) {
+					/* :711-803 suspend this photon, go on with the leaked fraction in capillary (qn, rn) */
+					pc_frame_save(cx.frames + (long)L.lvl*fstride, ph, L.h, L.calls, keep, L.entrance);
+					L.lvl++;
+					L.wts = wl;
+					ph.wmem = wl;
+					ph.Px = lx; ph.Py = ly; ph.Pz = lz;
+					ph.dtravel = ph.dtravel + dtr;
+					if (Pm.mono) { ph.kx = 0.; ph.ky = 0.; }
+					else { ph.ky = (3./2) * rn; ph.kx = (2.*qn + rn) * PC_COSPI_6; }
+					ph.kn = sqrt(ph.kx*ph.kx + ph.ky*ph.ky);
+					pc_set_boundary_flag(Pm, ph);
+					ph.i = pc_node_find(T, nmax + 1, lz);
+					L.calls = nmax + 1 - ph.i;
+					ph.rc = 0;
+					L.entrance = 0;
+					pc_trace_begin(ph);
+					L.st = (L.calls <= 0) ? PC_LS_ENDED : PC_LS_MARCH;
+					L.how = PC_END_CALLS;
+					break;
 				}
-			}
-			/* ---- no child: finish the reflection (src/polycap-capil.c:1345-1355) */
-			if (entrance) { ended = 1; how = PC_END_ABSORBED; entrance = 0; if (r < 0) how = PC_END_ERROR; }
-			else if (r < 0) { ended = 1; how = PC_END_ERROR; }
-			else if (r == 0) { ended = 1; how = PC_END_ABSORBED; }
-			else {
-				ph.dx = fma(-2.0*h.cosalfa, h.nx, ph.dx);
-				ph.dy = fma(-2.0*h.cosalfa, h.ny, ph.dy);
-				ph.dz = fma(-2.0*h.cosalfa, h.nz, ph.dz);
-				ph.irefl++;
-				ph.i = h.ix;
-				pc_trace_begin(ph);
-				st = PC_ST_MARCH;
-				continue;
 			}
 		}
-
-		/* ---- the photon being traced has ended */
+		/* no child: finish the reflection (:1345-1355) */
+		if (L.entrance) { L.entrance = 0; L.how = (r < 0) ? PC_END_ERROR : PC_END_ABSORBED; L.st = PC_LS_ENDED; }
+		else if (r < 0) { L.how = PC_END_ERROR; L.st = PC_LS_ENDED; }
+		else if (r == 0) { L.how = PC_END_ABSORBED; L.st = PC_LS_ENDED; }
+		else {
+			ph.dx = fma(-2.0*L.h.cosalfa, L.h.nx, ph.dx);
+			ph.dy = fma(-2.0*L.h.cosalfa, L.h.ny, ph.dy);
+			ph.dz = fma(-2.0*L.h.cosalfa, L.h.nz, ph.dz);
+			ph.irefl++;
+			ph.i = L.h.ix;
+			pc_trace_begin(ph);
+			if (L.calls <= 0) { L.how = PC_END_CALLS; L.st = PC_LS_ENDED; }
+			else L.st = PC_LS_MARCH;
+		}
+		break;
+	}
+	case PC_LS_INWALL_END: {
+		/* src/polycap-photon.c:676-806 */
+		const int wt = L.w.wt;
+		const double dtr = L.w.d_travel, qn = L.w.q_out, rn = L.w.r_out;
+		double *w = L.wts;
+		if (wt <= 0) { ph.rc = -1; L.rc = -1; L.st = PC_LS_DONE; break; }
+		for (int e = 0; e < ne; e++) w[e] = w[e] * exp(-1.*dtr*cx.amu[e]);
+		const double f = dtr / sqrt(ph.dx*ph.dx + ph.dy*ph.dy + ph.dz*ph.dz);
+		ph.Px = ph.Px + f*ph.dx; ph.Py = ph.Py + f*ph.dy; ph.Pz = ph.Pz + f*ph.dz;
+		if (wt == 3) pc_leak_emit(cx, PC_LEAK_EXT, ph.Px, ph.Py, ph.Pz, ph.dx, ph.dy, ph.dz, ph.ex, ph.ey, ph.ez, ph.irefl, w);
+		if (wt == 2) pc_leak_emit(cx, PC_LEAK_INT, ph.Px, ph.Py, ph.Pz, ph.dx, ph.dy, ph.dz, ph.ex, ph.ey, ph.ez, ph.irefl, w);
+		if (wt == 1) {
+			ph.dtravel = ph.dtravel + dtr;
+			ph.ky = rn * (3./2);
+			ph.kx = (2.*qn + rn) * PC_COSPI_6;
+			ph.kn = sqrt(ph.kx*ph.kx + ph.ky*ph.ky);
+			pc_set_boundary_flag(Pm, ph);
+			ph.i = pc_node_find(T, nmax + 1, ph.Pz);
+			ph.rc = 0;
+			pc_trace_begin(ph);
+			L.st = PC_LS_MARCH;
+		} else {
+			L.have_final = 3;        /* nothing to trace: straight to the common tail of :860-870 */
+			L.how = PC_END_CALLS;
+			L.st = PC_LS_ENDED;
+		}
+		break;
+	}
+	case PC_LS_ENDED: {
+		/* the photon being traced has ended */
 		for (;;) {
-			if (lvl == 0) {
-				if (have_final == 1)                    /* entrance reflection: launch returns 2 whatever happened inside */
-					{ if (how == PC_END_ERROR) pc_leak_emit(cx, PC_LEAK_VOID, 0,0,0, 0,0,0, 0,0,0, 0, nullptr); return 2; }
-				if (how == PC_END_ERROR) { pc_leak_emit(cx, PC_LEAK_VOID, 0,0,0, 0,0,0, 0,0,0, 0, nullptr); ph.rc = -1; return -1; }
-				if (have_final >= 2) {
+			double *w = L.wts;
+			if (L.lvl == 0) {
+				if (L.have_final == 1) {                  /* entrance reflection: launch returns 2 whatever happened inside */
+					if (L.how == PC_END_ERROR && cx.seq > 0) pc_leak_emit(cx, PC_LEAK_VOID, 0,0,0, 0,0,0, 0,0,0, 0, nullptr);
+					ph.rc = 2; L.rc = 2; L.st = PC_LS_DONE; break;
+				}
+				if (L.how == PC_END_ERROR) {
+					if (cx.seq > 0) pc_leak_emit(cx, PC_LEAK_VOID, 0,0,0, 0,0,0, 0,0,0, 0, nullptr);
+					ph.rc = -1; L.rc = -1; L.st = PC_LS_DONE; break;
+				}
+				if (L.have_final >= 2) {
 					/* src/polycap-photon.c:808-870: a photon launched inside the glass ends as a leak event itself */
-					if (have_final == 2 && (how == PC_END_CALLS || how == PC_END_EXIT)) {
+					if (L.have_final == 2 && (L.how == PC_END_CALLS || L.how == PC_END_EXIT)) {
 						const double t = (T.z[nmax]-ph.Pz)/ph.dz;
 						ph.Px = ph.Px + ph.dx * t; ph.Py = ph.Py + ph.dy * t; ph.Pz = ph.Pz + ph.dz * t;
 						const int inside = (T.ext[nmax] <= 0.) ? -1 : (pc_outside_hex(T.ext[nmax], ph.Px, ph.Py) ? 0 : 1);
@@ -526,50 +670,76 @@ PC_HD int pc_leak_launch(const pc_tables &T, const pc_params &Pm, pc_leak_ctx &c
 					}
 					for (int e = 0; e < ne; e++) w[e] = 0.;
 					ph.Px = T.ext[nmax]+1.; ph.Py = T.ext[nmax]+1.; ph.Pz = T.z[nmax];
-					ph.dx = sdx; ph.dy = sdy; ph.dz = sdz;
-					ph.rc = 1;
-					return 1;
+					ph.dx = L.sdx; ph.dy = L.sdy; ph.dz = L.sdz;
+					ph.rc = 1; L.rc = 1; L.st = PC_LS_DONE; break;
 				}
-				ph.rc = (how == PC_END_ABSORBED) ? 0 : 1;
-				return ph.rc;
+				ph.rc = (L.how == PC_END_ABSORBED) ? 0 : 1;
+				L.rc = ph.rc; L.st = PC_LS_DONE; break;
 			}
 			/* a leaked fraction has ended: src/polycap-capil.c:810-880 */
-			if (how == PC_END_ERROR) {
+			if (L.how == PC_END_ERROR) {
 				/* reflect returns -2 -> the parent's trace returns -1 -> ... : the whole launch fails */
-				lvl = 0;
+				L.lvl = 0;
+				L.wts = cx.frames + PC_LF_HDR;
 				continue;
 			}
 			double cxl = 0., cyl = 0., czl = 0.;
 			int final_kind = -2;
-			if (how == PC_END_CALLS || how == PC_END_EXIT) {
+			if (L.how == PC_END_CALLS || L.how == PC_END_EXIT) {
 				const double t = (T.z[nmax]-ph.Pz)/ph.dz;
 				cxl = ph.Px + ph.dx * t; cyl = ph.Py + ph.dy * t; czl = ph.Pz + ph.dz * t;
 				const int inside = (T.ext[nmax] <= 0.) ? -1 : (pc_outside_hex(T.ext[nmax], cxl, cyl) ? 0 : 1);
 				final_kind = (inside == 0) ? PC_LEAK_EXT : ((inside == 1) ? PC_LEAK_INT : -2);
 			}
 			const double *wchild = w;
-			lvl--;
+			L.lvl--;
 			int keep;
-			pc_frame_load(cx.frames + (long)lvl*fstride, ph, h, calls, keep, entrance);
-			w = cx.frames + (long)lvl*fstride + PC_LF_HDR;
-			ph.wmem = w;
+			pc_frame_load(cx.frames + (long)L.lvl*fstride, ph, L.h, L.calls, keep, L.entrance);
+			L.wts = cx.frames + (long)L.lvl*fstride + PC_LF_HDR;
+			ph.wmem = L.wts;
 			/* its last state is one more event, with THIS photon's direction, electric vector and reflection count */
 			if (final_kind != -2)
 				pc_leak_emit(cx, final_kind, cxl, cyl, czl, ph.dx, ph.dy, ph.dz, ph.ex, ph.ey, ph.ez, ph.irefl, wchild);
 			/* resume the suspended reflection where it stopped */
-			if (entrance) { how = PC_END_ABSORBED; entrance = 0; continue; }
-			if (keep == 0) { how = PC_END_ABSORBED; continue; }
-			ph.dx = fma(-2.0*h.cosalfa, h.nx, ph.dx);
-			ph.dy = fma(-2.0*h.cosalfa, h.ny, ph.dy);
-			ph.dz = fma(-2.0*h.cosalfa, h.nz, ph.dz);
+			if (L.entrance) { L.how = PC_END_ABSORBED; L.entrance = 0; continue; }
+			if (keep == 0) { L.how = PC_END_ABSORBED; continue; }
+			ph.dx = fma(-2.0*L.h.cosalfa, L.h.nx, ph.dx);
+			ph.dy = fma(-2.0*L.h.cosalfa, L.h.ny, ph.dy);
+			ph.dz = fma(-2.0*L.h.cosalfa, L.h.nz, ph.dz);
 			ph.irefl++;
-			ph.i = h.ix;
+			ph.i = L.h.ix;
 			ph.rc = 0;
 			pc_trace_begin(ph);
-			st = PC_ST_MARCH;
+			if (L.calls <= 0) { L.how = PC_END_CALLS; continue; }
+			L.st = PC_LS_MARCH;
 			break;
 		}
+		break;
 	}
+	default:
+		break;
+	}
+}
+
+/* one march step of a lane in PC_LS_MARCH */
+PC_HD void pc_leak_unit_march(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L)
+{
+	const int st = pc_march_step(T, Pm, L.ph);
+	if (st == PC_ST_EVENT) L.st = PC_LS_EVENT;
+	else if (st == PC_ST_DONE) { L.calls--; L.how = (L.ph.rc == 1) ? PC_END_EXIT : PC_END_ERROR; L.st = PC_LS_ENDED; }
+}
+
+/* the whole launch on one lane, unit after unit: the sequential algorithm (used by the host compile of the tests) */
+PC_HD int pc_leak_launch(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L, int st0, double z0)
+{
+	pc_leak_begin(T, Pm, L, st0, z0);
+	while (L.st != PC_LS_DONE) {
+		if (L.st == PC_LS_MARCH) pc_leak_unit_march(T, Pm, L);
+		else if (L.st == PC_LS_WALL_STEP) L.st = pc_wall_step(T, Pm, L, L.after_wall);
+		else if (L.st == PC_LS_WALL_PROBE) L.st = pc_wall_probe(T, Pm, L, L.after_wall);
+		else pc_leak_unit_other(T, Pm, L);
+	}
+	return L.rc;
 }
 
 #endif /* PC_LEAK_H */

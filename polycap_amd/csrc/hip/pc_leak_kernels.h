@@ -2,13 +2,14 @@
  * pc_leak_kernels.h -- leak_calc=true on the device: kernel + host code, included by pc_kernels.hip after the
  * context definition (same translation unit, so the two modes share tables, totals and image records).
  *
- * Shape.  The leak run of one launched photon (pc_leak.h) is a long, irregular, strictly sequential job: thousands
- * of cap/10 steps through the glass per reflection, a depth-first tree of leaked fractions, every decision discrete.
- * So this kernel does not schedule phases across a wave like pc_trace_kernel; every lane owns one exit-photon slot at
- * a time (taken from the same global counter), runs it to the end and appends its leak events to the record buffer.
- * What keeps the machine busy is the number of independent lanes, bounded only by the HBM given to the per-lane stacks
- * (max_depth x (24 + n_energies) doubles each).  All seven profile tables sit in LDS, including ext, which the wall
- * search reads at every step.
+ * Shape.  The leak run of one launched photon (pc_leak.h) is a long, irregular, strictly sequential job: blocks and
+ * steps through the glass for every reflection, a depth-first tree of leaked fractions, every decision discrete.  A lane
+ * owns one exit-photon slot at a time (taken from the global counter) and carries its whole state (pc_leak_lane) in
+ * registers; the wave is scheduled by KIND OF WORK like pc_trace_kernel: ballots count the lanes waiting for a wall
+ * step, a capillary probe, a march step or one of the short bookkeeping states, the most populated class runs a burst,
+ * so the 64 photons of a wave do not serialise each other.  The number of independent lanes is bounded by the HBM given
+ * to the per-lane stacks (max_depth x (24 + n_energies) doubles each).  All seven profile tables sit in LDS, including
+ * ext, which the wall search reads at every step.
  */
 #ifndef PC_LEAK_KERNELS_H
 #define PC_LEAK_KERNELS_H
@@ -27,6 +28,9 @@ struct pc_leak_kargs {
 	long long capacity;
 	unsigned int *final_attempt;   /* [n_slots]: attempt index of the transmitted photon of each slot (driver mode) */
 };
+
+/* lane modes of the scheduler on top of pc_leak_lane::st */
+enum { PC_LM_NEED = 0, PC_LM_RUN = 1, PC_LM_IDLE = 2 };
 
 template <int MODE, int PITCH>
 __global__ void __launch_bounds__(PC_LEAK_BLOCK)
@@ -55,96 +59,181 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 	const int ne = Pm.n_energies;
 	const long long rec = PC_N_FIELDS + (long long)ne;
 	const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int lane = threadIdx.x & (PC_WAVE - 1);
 
-	pc_leak_ctx cx;
-	cx.ec = a.ec; cx.amu = lk.amu; cx.ne = ne;
-	cx.frames = lk.frames + gtid * (long long)lk.max_depth * (PC_LF_HDR + ne);
-	cx.max_depth = lk.max_depth;
-	cx.sink.records = lk.records; cx.sink.cursor = lk.cursor; cx.sink.capacity = lk.capacity;
-	cx.stack_overflow = 0;
-	const double *w0 = cx.frames + PC_LF_HDR;      /* weights of the launched photon */
+	pc_leak_lane L;
+	L.cx.ec = a.ec; L.cx.amu = lk.amu; L.cx.ne = ne;
+	L.cx.frames = lk.frames + gtid * (long long)lk.max_depth * (PC_LF_HDR + ne);
+	L.cx.max_depth = lk.max_depth;
+	L.cx.sink.records = lk.records; L.cx.sink.cursor = lk.cursor; L.cx.sink.capacity = lk.capacity;
+	L.cx.stack_overflow = 0;
+	L.cx.seq = 0; L.cx.slot = 0.; L.cx.attempt = 0.;
+	L.st = PC_LS_DONE;
+	L.ph.wmem = nullptr; L.ph.wstride = 1; L.ph.wset = 0; L.ph.rc = 0;
+	const double *w0 = L.cx.frames + PC_LF_HDR;      /* weights of the launched photon */
 
+	int mode = PC_LM_NEED;
+	int launched = 0;                 /* a launch of this lane has finished and waits for the driver's verdict */
+	long long slot = -1;
+	unsigned int attempt = 0;
+	double cosalpha0 = 0.;
 	unsigned int n_exit = 0, n_not_entered = 0, n_not_trans = 0, n_failed = 0, n_launch = 0;
 	unsigned long long s_irefl = 0;
+	unsigned long long st_units[4] = {0, 0, 0, 0}, st_lanes[4] = {0, 0, 0, 0};   /* scheduler statistics per class */
 
 	for (;;) {
-		const long long slot = (long long)atomicAdd(&a.totals->next_slot, 1ull);
-		if (slot >= a.n_slots) break;
-		pc_photon<0> ph;
-		ph.wmem = nullptr; ph.wstride = 1; ph.wset = 0; ph.rc = 0;
-		if (EXPLICIT) {
-			const long long j = slot;
-			n_launch++;
-			const double z0 = a.in_start[3*j+2];
-			const int st = pc_launch_init(T, Pm, ph, a.in_start[3*j], a.in_start[3*j+1], z0, a.in_dir[3*j], a.in_dir[3*j+1], a.in_dir[3*j+2],
-			                              a.in_elecv[3*j], a.in_elecv[3*j+1], a.in_elecv[3*j+2]);
-			cx.slot = (double)j; cx.attempt = 0.;
-			const int rc = pc_leak_launch(T, Pm, cx, ph, st, z0);
-			a.out_rc[j] = rc;
-			for (int e = 0; e < ne; e++) a.out_weights[j*ne + e] = w0[e];
-			a.out_exit_coords[3*j] = ph.Px; a.out_exit_coords[3*j+1] = ph.Py; a.out_exit_coords[3*j+2] = ph.Pz;
-			a.out_exit_dir[3*j] = ph.dx; a.out_exit_dir[3*j+1] = ph.dy; a.out_exit_dir[3*j+2] = ph.dz;
-			a.out_exit_elecv[3*j] = ph.ex; a.out_exit_elecv[3*j+1] = ph.ey; a.out_exit_elecv[3*j+2] = ph.ez;
-			a.out_irefl[j] = ph.irefl;
-			a.out_dtravel[j] = ph.dtravel;
-			continue;
-		}
-		/* src/polycap-source.c:744-884, leak_calc=true */
-		unsigned int attempt = 0;
-		int ok = 0;
-		for (; attempt < a.max_attempts; attempt++) {
-			n_launch++;
-			pc_start s;
-			pc_sample_photon<MODE == PC_MODE_SRC_GENERIC>(Pm, a.seed, (unsigned long long)(a.slot0 + slot), attempt, s);
-			const int st = pc_launch_init(T, Pm, ph, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez);
-			const double cosalpha0 = s.ex*s.dx + s.ey*s.dy + s.ez*s.dz;
-			cx.slot = (double)(a.slot0 + slot); cx.attempt = (double)attempt;
-			const int rc = pc_leak_launch(T, Pm, cx, ph, st, s.z);
-			if (rc == 0) n_not_trans++;
-			else if (rc == 2) n_not_entered++;
-			else if (rc == 1) ok = pc_in_exit_window(Pm, ph);
-			if (!ok) continue;
-			n_exit++;
-			s_irefl += (unsigned long long)ph.irefl;
-			for (int e = 0; e < ne; e++) {
-				const double w = w0[e];
-				pc_atomic_add128(a.sumw + 2*e, (unsigned long long)(w * PC_FIX_SCALE), 0ull);
-				if (a.keep_images) a.img[slot*rec + PC_F_WEIGHTS + e] = w;
+		if (mode == PC_LM_RUN && L.st == PC_LS_DONE) { mode = PC_LM_NEED; launched = 1; }
+		const unsigned long long mM = __ballot(mode == PC_LM_RUN && L.st == PC_LS_MARCH);
+		const unsigned long long mS = __ballot(mode == PC_LM_RUN && L.st == PC_LS_WALL_STEP);
+		const unsigned long long mP = __ballot(mode == PC_LM_RUN && L.st == PC_LS_WALL_PROBE);
+		const unsigned long long mO = __ballot(mode == PC_LM_RUN && L.st != PC_LS_MARCH && L.st != PC_LS_WALL_STEP && L.st != PC_LS_WALL_PROBE);
+		const unsigned long long mN = __ballot(mode == PC_LM_NEED);
+		if ((mM | mS | mP | mO | mN) == 0ull) break;
+		const int nM = __popcll(mM), nS = __popcll(mS), nP = __popcll(mP), nO = __popcll(mO), nN = __popcll(mN);
+		/* the short states unblock lanes for the long ones: they count double */
+		const int best = max(max(nM, nS), max(nP, 2*max(nO, nN)));
+		if (nS > 0 && nS == best) {
+			/* ---- wall search: blocks / steps through the glass */
+			const int stop = (nS + 1) / 2;
+			for (int b = 0; b < 32; b++) {
+				if (mode == PC_LM_RUN && L.st == PC_LS_WALL_STEP)
+					L.st = pc_wall_step(T, Pm, L, L.after_wall);
+				const int c = __popcll(__ballot(mode == PC_LM_RUN && L.st == PC_LS_WALL_STEP));
+				st_units[0]++; st_lanes[0] += (unsigned)c;
+				if (c < stop) break;
 			}
-			if (a.keep_images) {
-				/* src/polycap-source.c:779-798, 900-923 */
-				double *r = a.img + slot*rec;
-				const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
-				r[PC_F_SRCX] = s.srcx; r[PC_F_SRCY] = s.srcy;
-				r[PC_F_STARTX] = s.x; r[PC_F_STARTY] = s.y;
-				r[PC_F_SDIRX] = s.dx; r[PC_F_SDIRY] = s.dy;
-				double tx = s.ex*c_ae + s.dx*c_be, ty = s.ey*c_ae + s.dy*c_be, tz = s.ez*c_ae + s.dz*c_be;
-				pc_norm3(tx, ty, tz);
-				r[PC_F_SEVX] = round(tx); r[PC_F_SEVY] = round(ty);
-				const double t = (Pm.z_end - ph.Pz) / ph.dz;
-				const double ex = ph.Px + ph.dx*t, ey = ph.Py + ph.dy*t, ez = ph.Pz + ph.dz*t;
-				r[PC_F_EXITX] = ex; r[PC_F_EXITY] = ey; r[PC_F_EXITZ] = ez;
-				r[PC_F_EDIRX] = ph.dx; r[PC_F_EDIRY] = ph.dy;
-				tx = ph.ex*c_ae + ph.dx*c_be; ty = ph.ey*c_ae + ph.dy*c_be; tz = ph.ez*c_ae + ph.dz*c_be;
-				pc_norm3(tx, ty, tz);
-				r[PC_F_EEVX] = round(tx); r[PC_F_EEVY] = round(ty);
-				((long long *)r)[PC_F_NREFL] = ph.irefl;
-				const double lx = ex - ph.Px, ly = ey - ph.Py, lz = Pm.z_end - ph.Pz;
-				r[PC_F_DTRAVEL] = ph.dtravel + sqrt(lx*lx + ly*ly + lz*lz);
+		} else if (nP > 0 && nP == best) {
+			/* ---- wall search: segments of the neighbouring capillary */
+			const int stop = (nP + 1) / 2;
+			for (int b = 0; b < 32; b++) {
+				if (mode == PC_LM_RUN && L.st == PC_LS_WALL_PROBE)
+					L.st = pc_wall_probe(T, Pm, L, L.after_wall);
+				const int c = __popcll(__ballot(mode == PC_LM_RUN && L.st == PC_LS_WALL_PROBE));
+				st_units[1]++; st_lanes[1] += (unsigned)c;
+				if (c < stop) break;
 			}
-			break;
-		}
-		lk.final_attempt[slot] = attempt;
-		if (!ok) {
-			n_failed++;
-			if (a.keep_images)
-				for (int e = 0; e < ne; e++) a.img[slot*rec + PC_F_WEIGHTS + e] = 0.;
+		} else if (nM > 0 && nM == best) {
+			/* ---- certified march between interactions */
+			const int stop = (nM + 1) / 2;
+			for (int b = 0; b < 32; b++) {
+				if (mode == PC_LM_RUN && L.st == PC_LS_MARCH)
+					pc_leak_unit_march(T, Pm, L);
+				const int c = __popcll(__ballot(mode == PC_LM_RUN && L.st == PC_LS_MARCH));
+				st_units[2]++; st_lanes[2] += (unsigned)c;
+				if (c < stop) break;
+			}
+		} else if (nO > 0 && nO >= nN) {
+			/* ---- segment visits, reflections with their leak bookkeeping, end of a photon */
+			st_units[3]++; st_lanes[3] += (unsigned)nO;
+			if (mode == PC_LM_RUN && L.st != PC_LS_MARCH && L.st != PC_LS_WALL_STEP && L.st != PC_LS_WALL_PROBE)
+				pc_leak_unit_other(T, Pm, L);
+		} else {
+			/* ---- driver: verdict on finished launches, next attempt or next slot */
+			if (mode == PC_LM_NEED) {
+				int need_slot = 1;
+				if (launched) {
+					launched = 0;
+					const int rc = L.rc;
+					if (EXPLICIT) {
+						const long long j = slot;
+						a.out_rc[j] = rc;
+						for (int e = 0; e < ne; e++) a.out_weights[j*ne + e] = w0[e];
+						a.out_exit_coords[3*j] = L.ph.Px; a.out_exit_coords[3*j+1] = L.ph.Py; a.out_exit_coords[3*j+2] = L.ph.Pz;
+						a.out_exit_dir[3*j] = L.ph.dx; a.out_exit_dir[3*j+1] = L.ph.dy; a.out_exit_dir[3*j+2] = L.ph.dz;
+						a.out_exit_elecv[3*j] = L.ph.ex; a.out_exit_elecv[3*j+1] = L.ph.ey; a.out_exit_elecv[3*j+2] = L.ph.ez;
+						a.out_irefl[j] = L.ph.irefl;
+						a.out_dtravel[j] = L.ph.dtravel;
+					} else {
+						/* src/polycap-source.c:758-777 */
+						int ok = 0;
+						if (rc == 0) n_not_trans++;
+						else if (rc == 2) n_not_entered++;
+						else if (rc == 1) ok = pc_in_exit_window(Pm, L.ph);
+						if (ok) {
+							n_exit++;
+							s_irefl += (unsigned long long)L.ph.irefl;
+							for (int e = 0; e < ne; e++) {
+								const double w = w0[e];
+								pc_atomic_add128(a.sumw + 2*e, (unsigned long long)(w * PC_FIX_SCALE), 0ull);
+								if (a.keep_images) a.img[slot*rec + PC_F_WEIGHTS + e] = w;
+							}
+							if (a.keep_images) {
+								/* src/polycap-source.c:900-923 */
+								double *r = a.img + slot*rec;
+								const pc_photon<0> &ph = L.ph;
+								const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
+								const double t = (Pm.z_end - ph.Pz) / ph.dz;
+								const double ex = ph.Px + ph.dx*t, ey = ph.Py + ph.dy*t, ez = ph.Pz + ph.dz*t;
+								r[PC_F_EXITX] = ex; r[PC_F_EXITY] = ey; r[PC_F_EXITZ] = ez;
+								r[PC_F_EDIRX] = ph.dx; r[PC_F_EDIRY] = ph.dy;
+								double tx = ph.ex*c_ae + ph.dx*c_be, ty = ph.ey*c_ae + ph.dy*c_be, tz = ph.ez*c_ae + ph.dz*c_be;
+								pc_norm3(tx, ty, tz);
+								r[PC_F_EEVX] = round(tx); r[PC_F_EEVY] = round(ty);
+								((long long *)r)[PC_F_NREFL] = ph.irefl;
+								const double lx = ex - ph.Px, ly = ey - ph.Py, lz = Pm.z_end - ph.Pz;
+								r[PC_F_DTRAVEL] = ph.dtravel + sqrt(lx*lx + ly*ly + lz*lz);
+							}
+							lk.final_attempt[slot] = attempt;
+						} else {
+							attempt++;
+							if (attempt >= a.max_attempts) {
+								n_failed++;
+								lk.final_attempt[slot] = attempt;
+								if (a.keep_images)
+									for (int e = 0; e < ne; e++) a.img[slot*rec + PC_F_WEIGHTS + e] = 0.;
+							} else {
+								need_slot = 0;
+							}
+						}
+					}
+				}
+				if (need_slot) {
+					slot = (long long)atomicAdd(&a.totals->next_slot, 1ull);
+					attempt = 0;
+					if (slot >= a.n_slots) mode = PC_LM_IDLE;
+				}
+				if (mode != PC_LM_IDLE) {
+					/* start an attempt */
+					n_launch++;
+					double z0;
+					int st;
+					if (EXPLICIT) {
+						const long long j = slot;
+						z0 = a.in_start[3*j+2];
+						st = pc_launch_init(T, Pm, L.ph, a.in_start[3*j], a.in_start[3*j+1], z0, a.in_dir[3*j], a.in_dir[3*j+1], a.in_dir[3*j+2],
+						                    a.in_elecv[3*j], a.in_elecv[3*j+1], a.in_elecv[3*j+2]);
+						L.cx.slot = (double)j; L.cx.attempt = 0.;
+					} else {
+						pc_start s;
+						pc_sample_photon<MODE == PC_MODE_SRC_GENERIC>(Pm, a.seed, (unsigned long long)(a.slot0 + slot), attempt, s);
+						z0 = s.z;
+						st = pc_launch_init(T, Pm, L.ph, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez);
+						L.cx.slot = (double)(a.slot0 + slot); L.cx.attempt = (double)attempt;
+						if (st == PC_ST_MARCH) {
+							/* src/polycap-source.c:779-798: start images of the attempt that is now inside a capillary; the slot
+							 * belongs to this lane, so a later (transmitted) attempt simply overwrites them */
+							cosalpha0 = s.ex*s.dx + s.ey*s.dy + s.ez*s.dz;
+							if (a.keep_images) {
+								const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
+								double *r = a.img + slot*rec;
+								r[PC_F_SRCX] = s.srcx; r[PC_F_SRCY] = s.srcy;
+								r[PC_F_STARTX] = s.x; r[PC_F_STARTY] = s.y;
+								r[PC_F_SDIRX] = s.dx; r[PC_F_SDIRY] = s.dy;
+								double tx = s.ex*c_ae + s.dx*c_be, ty = s.ey*c_ae + s.dy*c_be, tz = s.ez*c_ae + s.dz*c_be;
+								pc_norm3(tx, ty, tz);
+								r[PC_F_SEVX] = round(tx); r[PC_F_SEVY] = round(ty);
+							}
+						}
+					}
+					pc_leak_begin(T, Pm, L, st, z0);
+					mode = PC_LM_RUN;
+				}
+			}
 		}
 	}
 
-	if (cx.stack_overflow) atomicAdd(&lk.cursor[1], 1ull);
+	if (L.cx.stack_overflow) atomicAdd(&lk.cursor[1], 1ull);
 	if (!EXPLICIT) {
-		const int lane = threadIdx.x & (PC_WAVE - 1);
 		unsigned long long v0 = pc_wave_sum_u64(n_exit), v1 = pc_wave_sum_u64(n_not_entered), v2 = pc_wave_sum_u64(n_not_trans);
 		unsigned long long v3 = pc_wave_sum_u64(s_irefl), v4 = pc_wave_sum_u64(n_failed), v5 = pc_wave_sum_u64(n_launch);
 		if (lane == 0) {
@@ -154,6 +243,11 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 			atomicAdd(&a.totals->counters[3], v3);
 			if (v4) atomicAdd(&a.totals->counters[4], v4);
 			atomicAdd(&a.totals->counters[5], v5);
+			/* scheduler statistics (pc_hip_phase_stats): units and lane-units of wall steps, wall probes, march */
+			atomicAdd(&a.totals->phase[0], st_units[0]); atomicAdd(&a.totals->phase[1], st_lanes[0]);
+			atomicAdd(&a.totals->phase[2], st_units[1]); atomicAdd(&a.totals->phase[3], st_lanes[1]);
+			atomicAdd(&a.totals->phase[4], st_units[2]); atomicAdd(&a.totals->phase[5], st_lanes[2]);
+			atomicAdd(&a.totals->phase[6], st_units[3]); atomicAdd(&a.totals->phase[7], st_lanes[3]);
 		}
 	}
 }

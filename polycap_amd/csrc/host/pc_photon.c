@@ -5,7 +5,7 @@
  * polycap_photon_launch :390-955, getters :958-1013, leak getters :1037-1121, free.
  * polycap_photon_launch does not trace on the CPU: it hands the photon to the HIP kernel through
  * pc_hip_launch_photons (a batch of one) and copies the final state back into the photon.
- * The leak ("halo") calculation (leak_calc = true) is not part of this build yet.
+ * leak_calc = true runs the leak ("halo") kernel (pc_hip_launch_photons_leak); its events become photon->extleak / intleak.
  */
 #include "pc_private.h"
 
@@ -70,10 +70,11 @@ int polycap_photon_launch(polycap_photon *photon, size_t n_energies, double *ene
 		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_photon_launch: weights cannot be NULL");
 		return -1;
 	}
-	if (leak_calc) {
-		polycap_set_error_literal(error, POLYCAP_ERROR_UNSUPPORTED, "polycap_photon_launch: leak_calc=true (halo photons) is not implemented in the MI355X build");
-		return -1;
-	}
+	/* events of an earlier launch of the same photon are dropped (reference :434-450) */
+	pc_leak_list_free(photon->extleak, photon->n_extleak);
+	pc_leak_list_free(photon->intleak, photon->n_intleak);
+	photon->extleak = photon->intleak = NULL;
+	photon->n_extleak = photon->n_intleak = 0;
 	polycap_description *description = photon->description;
 	if (description == NULL) {
 		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_photon_launch: description cannot be NULL");
@@ -102,10 +103,17 @@ int polycap_photon_launch(polycap_photon *photon, size_t n_energies, double *ene
 	double exit_coords[3], exit_dir[3], exit_elecv[3], d_travel = 0.;
 	int32_t rc = -1;
 	int64_t i_refl = 0;
-	int status = pc_hip_launch_photons(ctx, 1, start, dir, elecv, &rc, *weights, exit_coords, exit_dir, exit_elecv, &i_refl, &d_travel);
+	int status = leak_calc
+		? pc_hip_launch_photons_leak(ctx, 1, start, dir, elecv, &rc, *weights, exit_coords, exit_dir, exit_elecv, &i_refl, &d_travel)
+		: pc_hip_launch_photons(ctx, 1, start, dir, elecv, &rc, *weights, exit_coords, exit_dir, exit_elecv, &i_refl, &d_travel);
 	if (status != PC_HIP_OK) {
 		pc_set_hip_error(error, "polycap_photon_launch", status);
 		return -1;
+	}
+	if (leak_calc) {
+		if (pc_fetch_leaks(ctx, 0, n_energies, &photon->extleak, &photon->n_extleak, NULL, "polycap_photon_launch", error) != 0 ||
+		    pc_fetch_leaks(ctx, 1, n_energies, &photon->intleak, &photon->n_intleak, NULL, "polycap_photon_launch", error) != 0)
+			return -1;
 	}
 
 	/* the reference normalises start_direction in place (src/polycap-photon.c:493) */
@@ -136,17 +144,114 @@ polycap_vector3 polycap_photon_get_exit_coords(polycap_photon *photon) { return 
 polycap_vector3 polycap_photon_get_exit_direction(polycap_photon *photon) { return photon->exit_direction; }
 polycap_vector3 polycap_photon_get_exit_electric_vector(polycap_photon *photon) { return photon->exit_electric_vector; }
 
-/* without the leak calculation a photon never carries leak events: same answer the reference gives for n_leaks == 0 */
+/* One polycap_leak per event record of include/polycap-hip.h (slot, attempt, coords, direction, elecv, n_refl, weights).
+ * slots (optional) receives the slot column.  Returns 0, or -1 with *error set. */
+int pc_fetch_leaks(pc_hip_ctx *ctx, int kind, size_t n_energies, polycap_leak ***list, int64_t *n, int64_t **slots,
+	const char *caller, polycap_error **error)
+{
+	int64_t n_ext = 0, n_int = 0;
+	*list = NULL;
+	*n = 0;
+	if (slots) *slots = NULL;
+	int status = pc_hip_leak_counts(ctx, &n_ext, &n_int);
+	if (status != PC_HIP_OK) {
+		pc_set_hip_error(error, caller, status);
+		return -1;
+	}
+	const int64_t count = (kind == 0) ? n_ext : n_int;
+	if (count == 0)
+		return 0;
+	const size_t stride = PC_HIP_LEAK_HDR + n_energies;
+	double *rec = malloc(sizeof(double) * stride * (size_t)count);
+	polycap_leak **out = calloc((size_t)count, sizeof(polycap_leak *));
+	int64_t *sl = slots ? malloc(sizeof(int64_t) * (size_t)count) : NULL;
+	if (rec == NULL || out == NULL || (slots && sl == NULL)) {
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "%s: could not allocate memory for leak events -> %s", caller, strerror(errno));
+		free(rec); free(out); free(sl);
+		return -1;
+	}
+	status = pc_hip_leak_events(ctx, kind, 0, count, rec);
+	if (status != PC_HIP_OK) {
+		pc_set_hip_error(error, caller, status);
+		free(rec); free(out); free(sl);
+		return -1;
+	}
+	for (int64_t k = 0; k < count; k++) {
+		const double *r = rec + (size_t)k * stride;
+		polycap_leak *l = malloc(sizeof(polycap_leak));
+		double *w = malloc(sizeof(double) * n_energies);
+		if (l == NULL || w == NULL) {
+			polycap_set_error(error, POLYCAP_ERROR_MEMORY, "%s: could not allocate memory for a leak event -> %s", caller, strerror(errno));
+			free(l); free(w);
+			pc_leak_list_free(out, k);
+			free(rec); free(sl);
+			return -1;
+		}
+		l->coords.x = r[2]; l->coords.y = r[3]; l->coords.z = r[4];
+		l->direction.x = r[5]; l->direction.y = r[6]; l->direction.z = r[7];
+		l->elecv.x = r[8]; l->elecv.y = r[9]; l->elecv.z = r[10];
+		l->n_refl = (int64_t)r[11];
+		l->n_energies = n_energies;
+		memcpy(w, r + PC_HIP_LEAK_HDR, sizeof(double) * n_energies);
+		l->weight = w;
+		out[k] = l;
+		if (sl) sl[k] = (int64_t)r[0];
+	}
+	free(rec);
+	*list = out;
+	*n = count;
+	if (slots) *slots = sl;
+	return 0;
+}
+
+void pc_leak_list_free(polycap_leak **list, int64_t n)
+{
+	if (list == NULL)
+		return;
+	for (int64_t k = 0; k < n; k++)
+		polycap_leak_free(list[k]);
+	free(list);
+}
+
+/* deep copy for the getters (reference :1037-1121): caller owns the result */
+bool pc_leak_list_copy(polycap_leak **src, int64_t n_src, polycap_leak ***leaks, int64_t *n_leaks, const char *caller, const char *what,
+	polycap_error **error)
+{
+	*n_leaks = n_src;
+	if (n_src == 0) {
+		*leaks = NULL;
+		polycap_set_error(error, POLYCAP_ERROR_INVALID_ARGUMENT, "%s: no %s events in photon", caller, what);
+		return false;
+	}
+	*leaks = malloc(sizeof(polycap_leak *) * (size_t)n_src);
+	if (*leaks == NULL) {
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "%s: could not allocate memory for leaks -> %s", caller, strerror(errno));
+		return false;
+	}
+	for (int64_t i = 0; i < n_src; i++) {
+		(*leaks)[i] = malloc(sizeof(polycap_leak));
+		if ((*leaks)[i] == NULL) {
+			polycap_set_error(error, POLYCAP_ERROR_MEMORY, "%s: could not allocate memory for (*leaks)[i] -> %s", caller, strerror(errno));
+			return false;
+		}
+		memcpy((*leaks)[i], src[i], sizeof(polycap_leak));
+		(*leaks)[i]->weight = malloc(sizeof(double) * src[i]->n_energies);
+		if ((*leaks)[i]->weight == NULL) {
+			polycap_set_error(error, POLYCAP_ERROR_MEMORY, "%s: could not allocate memory for (*leaks[i])->weight -> %s", caller, strerror(errno));
+			return false;
+		}
+		memcpy((*leaks)[i]->weight, src[i]->weight, sizeof(double) * src[i]->n_energies);
+	}
+	return true;
+}
+
 bool polycap_photon_get_extleak_data(polycap_photon *photon, polycap_leak ***leaks, int64_t *n_leaks, polycap_error **error)
 {
 	if (photon == NULL) {
 		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_photon_get_extleak_data: photon cannot be NULL");
 		return false;
 	}
-	if (n_leaks) *n_leaks = 0;
-	if (leaks) *leaks = NULL;
-	polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_photon_get_extleak_data: no extleak events in photon");
-	return false;
+	return pc_leak_list_copy(photon->extleak, photon->n_extleak, leaks, n_leaks, "polycap_photon_get_extleak_data", "extleak", error);
 }
 
 bool polycap_photon_get_intleak_data(polycap_photon *photon, polycap_leak ***leaks, int64_t *n_leaks, polycap_error **error)
@@ -155,10 +260,7 @@ bool polycap_photon_get_intleak_data(polycap_photon *photon, polycap_leak ***lea
 		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_photon_get_intleak_data: photon cannot be NULL");
 		return false;
 	}
-	if (n_leaks) *n_leaks = 0;
-	if (leaks) *leaks = NULL;
-	polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_photon_get_intleak_data: no intleak events in photon");
-	return false;
+	return pc_leak_list_copy(photon->intleak, photon->n_intleak, leaks, n_leaks, "polycap_photon_get_intleak_data", "intleak", error);
 }
 
 void polycap_leak_free(polycap_leak *leak)
@@ -177,5 +279,7 @@ void polycap_photon_free(polycap_photon *photon)
 	free(photon->weight);
 	free(photon->amu);
 	free(photon->scatf);
+	pc_leak_list_free(photon->extleak, photon->n_extleak);
+	pc_leak_list_free(photon->intleak, photon->n_intleak);
 	free(photon);
 }

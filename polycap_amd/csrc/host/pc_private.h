@@ -101,8 +101,19 @@ struct _polycap_images {
 	int64_t *pc_exit_nrefl;
 	double *pc_exit_dtravel;
 	double *exit_coord_weights;
+	/* leak_calc=true: events that left the optic through its side (extleak) or reached the exit plane inside the glass
+	 * (intleak); planes of i_extleak / i_intleak entries, weights row-major by event (reference :168-180) */
 	int64_t i_extleak;
 	int64_t i_intleak;
+	double *extleak_coords[3];
+	double *extleak_dir[2];
+	int64_t *extleak_n_refl;
+	double *extleak_coord_weights;
+	double *intleak_coords[3];
+	double *intleak_dir[2];
+	double *intleak_elecv[2];
+	int64_t *intleak_n_refl;
+	double *intleak_coord_weights;
 };
 
 struct _polycap_transmission_efficiencies {
@@ -130,6 +141,14 @@ POLYCAP_EXTERN const char *pc_hdf5_provider(void);
 polycap_transmission_efficiencies *pc_transeff_alloc(polycap_source *source, size_t np, const char *caller, polycap_error **error);
 void pc_transeff_plane_pointers(polycap_transmission_efficiencies *eff, pc_hip_images *dst);
 void pc_transeff_finish(polycap_transmission_efficiencies *eff, const double *sum_weights, const int64_t counters[6]);
+int pc_transeff_fetch_leaks(polycap_transmission_efficiencies *eff, pc_hip_ctx *ctx);   /* returns a pc_hip_status */
+
+/* leak events of the last leak_calc run of `ctx` as polycap_leak lists (pc_photon.c); *list is malloc'd, NULL when empty */
+int pc_fetch_leaks(pc_hip_ctx *ctx, int kind, size_t n_energies, polycap_leak ***list, int64_t *n, int64_t **slots,
+	const char *caller, polycap_error **error);
+void pc_leak_list_free(polycap_leak **list, int64_t n);
+bool pc_leak_list_copy(polycap_leak **src, int64_t n_src, polycap_leak ***leaks, int64_t *n_leaks, const char *caller, const char *what,
+	polycap_error **error);
 
 /* device context management */
 void pc_ctx_cache_clear(pc_ctx_cache *c);

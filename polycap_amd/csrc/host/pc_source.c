@@ -351,10 +351,6 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_transmission_efficiencies: n_photons must be greater than 1");
 		return NULL;
 	}
-	if (leak_calc) {
-		polycap_set_error_literal(error, POLYCAP_ERROR_UNSUPPORTED, "polycap_source_get_transmission_efficiencies: leak_calc=true (halo photons) is not implemented in the MI355X build");
-		return NULL;
-	}
 
 	const size_t ne = source->n_energies;
 	polycap_transmission_efficiencies *eff = pc_transeff_alloc(source, (size_t)n_photons, "polycap_source_get_transmission_efficiencies", error);
@@ -381,7 +377,8 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 	uint32_t max_attempts = (uint32_t)pc_env_u64("POLYCAP_MAX_ATTEMPTS", 1u << 20, NULL);
 
 	int64_t counters[6] = {0, 0, 0, 0, 0, 0};
-	int status = pc_hip_transmission_run(ctx, seed, 0, n_photons, max_attempts, 1);
+	int status = leak_calc ? pc_hip_transmission_run_leak(ctx, seed, 0, n_photons, max_attempts, 1)
+	                       : pc_hip_transmission_run(ctx, seed, 0, n_photons, max_attempts, 1);
 	if (status == PC_HIP_OK)
 		status = pc_hip_transmission_wait(ctx, NULL);
 	if (status == PC_HIP_OK)
@@ -391,6 +388,8 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 		pc_transeff_plane_pointers(eff, &dst);
 		status = pc_hip_transmission_images(ctx, 0, n_photons, &dst);
 	}
+	if (status == PC_HIP_OK && leak_calc)
+		status = pc_transeff_fetch_leaks(eff, ctx);      /* reference :925-1032 */
 	if (status != PC_HIP_OK) {
 		pc_set_hip_error(error, "polycap_source_get_transmission_efficiencies", status);
 		free(sum_weights);

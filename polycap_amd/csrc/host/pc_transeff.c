@@ -3,8 +3,8 @@
  *
  * Layout and getters follow the reference's src/polycap-transmission-efficiencies.c:782-1172:
  * SoA image planes indexed by exit-photon slot, exit_coord_weights row-major by photon; getters hand out
- * malloc'd copies (caller frees with polycap_free).  Leak planes are absent (leak_calc is unsupported), so the
- * leak getters report "no leak events" exactly as the reference does for an empty list.
+ * malloc'd copies (caller frees with polycap_free).  After a leak_calc run the leak planes hold the events of the run
+ * (extleak: coordinates, direction x/y, reflections, weights; intleak: the electric vector x/y as well).
  * The HDF5 writer (reference :38-780) lives in pc_hdf5.c.
  */
 #include "pc_private.h"
@@ -31,6 +31,19 @@ static void pc_images_free(struct _polycap_images *images)
 	free(images->pc_exit_nrefl);
 	free(images->pc_exit_dtravel);
 	free(images->exit_coord_weights);
+	for (int k = 0; k < 3; k++) {
+		free(images->extleak_coords[k]);
+		free(images->intleak_coords[k]);
+	}
+	for (int k = 0; k < 2; k++) {
+		free(images->extleak_dir[k]);
+		free(images->intleak_dir[k]);
+		free(images->intleak_elecv[k]);
+	}
+	free(images->extleak_n_refl);
+	free(images->extleak_coord_weights);
+	free(images->intleak_n_refl);
+	free(images->intleak_coord_weights);
 	free(images);
 }
 
@@ -280,6 +293,108 @@ bool polycap_transmission_efficiencies_get_exit_data(polycap_transmission_effici
 	return true;
 }
 
+/* Leak events of the finished leak_calc run of `ctx` -> the leak planes of eff->images (reference: src/polycap-source.c:
+ * 982-1032).  Fetched in blocks of records (include/polycap-hip.h) and scattered into the planes. */
+int pc_transeff_fetch_leaks(polycap_transmission_efficiencies *eff, pc_hip_ctx *ctx)
+{
+	struct _polycap_images *im = eff->images;
+	const size_t ne = eff->n_energies, stride = PC_HIP_LEAK_HDR + ne;
+	int64_t n_kind[2] = {0, 0};
+	int status = pc_hip_leak_counts(ctx, &n_kind[0], &n_kind[1]);
+	if (status != PC_HIP_OK)
+		return status;
+	const int64_t block = 65536;
+	double *rec = malloc(sizeof(double) * stride * (size_t)block);
+	if (rec == NULL)
+		return PC_HIP_ERR_MEMORY;
+	for (int kind = 0; kind < 2 && status == PC_HIP_OK; kind++) {
+		const size_t n = (size_t)n_kind[kind], nalloc = n ? n : 1;
+		double *coords[3], *dir[2], *elecv[2] = { NULL, NULL }, *w;
+		int64_t *nrefl;
+		int ok = 1;
+		for (int k = 0; k < 3; k++) { coords[k] = malloc(sizeof(double) * nalloc); ok = ok && coords[k] != NULL; }
+		for (int k = 0; k < 2; k++) { dir[k] = malloc(sizeof(double) * nalloc); ok = ok && dir[k] != NULL; }
+		if (kind == 1)
+			for (int k = 0; k < 2; k++) { elecv[k] = malloc(sizeof(double) * nalloc); ok = ok && elecv[k] != NULL; }
+		nrefl = malloc(sizeof(int64_t) * nalloc);
+		w = malloc(sizeof(double) * nalloc * ne);
+		ok = ok && nrefl != NULL && w != NULL;
+		/* hand the planes to the images first so that a failure below is cleaned up by polycap_transmission_efficiencies_free */
+		if (kind == 0) {
+			for (int k = 0; k < 3; k++) im->extleak_coords[k] = coords[k];
+			for (int k = 0; k < 2; k++) im->extleak_dir[k] = dir[k];
+			im->extleak_n_refl = nrefl; im->extleak_coord_weights = w; im->i_extleak = (int64_t)n;
+		} else {
+			for (int k = 0; k < 3; k++) im->intleak_coords[k] = coords[k];
+			for (int k = 0; k < 2; k++) { im->intleak_dir[k] = dir[k]; im->intleak_elecv[k] = elecv[k]; }
+			im->intleak_n_refl = nrefl; im->intleak_coord_weights = w; im->i_intleak = (int64_t)n;
+		}
+		if (!ok) { status = PC_HIP_ERR_MEMORY; break; }
+		for (int64_t first = 0; first < (int64_t)n && status == PC_HIP_OK; first += block) {
+			const int64_t count = ((int64_t)n - first < block) ? (int64_t)n - first : block;
+			status = pc_hip_leak_events(ctx, kind, first, count, rec);
+			if (status != PC_HIP_OK)
+				break;
+			for (int64_t k = 0; k < count; k++) {
+				const double *r = rec + (size_t)k * stride;
+				const size_t j = (size_t)(first + k);
+				coords[0][j] = r[2]; coords[1][j] = r[3]; coords[2][j] = r[4];
+				dir[0][j] = r[5]; dir[1][j] = r[6];
+				if (kind == 1) { elecv[0][j] = r[8]; elecv[1][j] = r[9]; }
+				nrefl[j] = (int64_t)r[11];
+				memcpy(w + j*ne, r + PC_HIP_LEAK_HDR, sizeof(double) * ne);
+			}
+		}
+	}
+	free(rec);
+	return status;
+}
+
+/* one malloc'd polycap_leak per stored event (reference :929-1058): direction.z and elecv.z are rebuilt from the two
+ * stored components; extleak events carry no electric vector in the images (zeros here) */
+static bool pc_transeff_leaks(polycap_transmission_efficiencies *efficiencies, int kind, polycap_leak ***leaks, int64_t *n_leaks,
+	const char *caller, const char *what, polycap_error **error)
+{
+	const struct _polycap_images *im = efficiencies->images;
+	const int64_t n = (kind == 0) ? im->i_extleak : im->i_intleak;
+	const size_t ne = efficiencies->n_energies;
+	*n_leaks = n;
+	if (n == 0) {
+		*leaks = NULL;
+		polycap_set_error(error, POLYCAP_ERROR_INVALID_ARGUMENT, "%s: no %s events in efficiencies", caller, what);
+		return false;
+	}
+	*leaks = malloc(sizeof(polycap_leak *) * (size_t)n);
+	if (*leaks == NULL) {
+		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "%s: could not allocate memory for leaks -> %s", caller, strerror(errno));
+		return false;
+	}
+	for (int64_t i = 0; i < n; i++) {
+		polycap_leak *l = calloc(1, sizeof(polycap_leak));
+		(*leaks)[i] = l;
+		if (l != NULL)
+			l->weight = malloc(sizeof(double) * ne);
+		if (l == NULL || l->weight == NULL) {
+			polycap_set_error(error, POLYCAP_ERROR_MEMORY, "%s: could not allocate memory for (*leaks)[i] -> %s", caller, strerror(errno));
+			return false;
+		}
+		if (kind == 0) {
+			l->coords.x = im->extleak_coords[0][i]; l->coords.y = im->extleak_coords[1][i]; l->coords.z = im->extleak_coords[2][i];
+			l->direction = pc_unit_from_xy(im->extleak_dir[0][i], im->extleak_dir[1][i]);
+			l->n_refl = im->extleak_n_refl[i];
+			memcpy(l->weight, im->extleak_coord_weights + (size_t)i*ne, sizeof(double) * ne);
+		} else {
+			l->coords.x = im->intleak_coords[0][i]; l->coords.y = im->intleak_coords[1][i]; l->coords.z = im->intleak_coords[2][i];
+			l->direction = pc_unit_from_xy(im->intleak_dir[0][i], im->intleak_dir[1][i]);
+			l->elecv = pc_unit_from_xy(im->intleak_elecv[0][i], im->intleak_elecv[1][i]);
+			l->n_refl = im->intleak_n_refl[i];
+			memcpy(l->weight, im->intleak_coord_weights + (size_t)i*ne, sizeof(double) * ne);
+		}
+		l->n_energies = ne;
+	}
+	return true;
+}
+
 bool polycap_transmission_efficiencies_get_extleak_data(polycap_transmission_efficiencies *efficiencies, polycap_leak ***leaks, int64_t *n_leaks, polycap_error **error)
 {
 	if (efficiencies == NULL) {
@@ -290,10 +405,7 @@ bool polycap_transmission_efficiencies_get_extleak_data(polycap_transmission_eff
 		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_extleak_data: source->images cannot be NULL");
 		return false;
 	}
-	if (n_leaks) *n_leaks = 0;
-	if (leaks) *leaks = NULL;
-	polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_extleak_data: no extleak events in efficiencies");
-	return false;
+	return pc_transeff_leaks(efficiencies, 0, leaks, n_leaks, "polycap_source_get_extleak_data", "extleak", error);
 }
 
 bool polycap_transmission_efficiencies_get_intleak_data(polycap_transmission_efficiencies *efficiencies, polycap_leak ***leaks, int64_t *n_leaks, polycap_error **error)
@@ -306,8 +418,5 @@ bool polycap_transmission_efficiencies_get_intleak_data(polycap_transmission_eff
 		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_intleak_data: source->images cannot be NULL");
 		return false;
 	}
-	if (n_leaks) *n_leaks = 0;
-	if (leaks) *leaks = NULL;
-	polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_getintleak_data: no intleak events in efficiencies");
-	return false;
+	return pc_transeff_leaks(efficiencies, 1, leaks, n_leaks, "polycap_source_get_intleak_data", "intleak", error);
 }

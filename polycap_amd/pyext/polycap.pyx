@@ -52,7 +52,17 @@ cdef extern from "polycap.h" nogil:
         double x
         double y
         double z
+    ctypedef struct polycap_leak:
+        polycap_vector3 coords
+        polycap_vector3 direction
+        polycap_vector3 elecv
+        size_t n_energies
+        double *weight
+        int64_t n_refl
+    void polycap_leak_free(polycap_leak *leak)
     ctypedef struct polycap_photon
+    cbool polycap_photon_get_extleak_data(polycap_photon *photon, polycap_leak ***leaks, int64_t *n_leaks, polycap_error **error)
+    cbool polycap_photon_get_intleak_data(polycap_photon *photon, polycap_leak ***leaks, int64_t *n_leaks, polycap_error **error)
     polycap_photon *polycap_photon_new(polycap_description *description, polycap_vector3 start_coords, polycap_vector3 start_direction,
         polycap_vector3 start_electric_vector, polycap_error **error)
     int polycap_photon_launch(polycap_photon *photon, size_t n_energies, double *energies, double **weights, cbool leak_calc, polycap_error **error)
@@ -73,6 +83,10 @@ cdef extern from "polycap.h" nogil:
 
     ctypedef struct polycap_transmission_efficiencies
     void polycap_transmission_efficiencies_free(polycap_transmission_efficiencies *efficiencies)
+    cbool polycap_transmission_efficiencies_get_extleak_data(polycap_transmission_efficiencies *efficiencies, polycap_leak ***leaks,
+        int64_t *n_leaks, polycap_error **error)
+    cbool polycap_transmission_efficiencies_get_intleak_data(polycap_transmission_efficiencies *efficiencies, polycap_leak ***leaks,
+        int64_t *n_leaks, polycap_error **error)
     cbool polycap_transmission_efficiencies_write_hdf5(polycap_transmission_efficiencies *efficiencies, const char *filename, polycap_error **error)
     cbool polycap_transmission_efficiencies_get_data(polycap_transmission_efficiencies *efficiencies, size_t *n_energies,
         double **energies_arr, double **efficiencies_arr, polycap_error **error)
@@ -162,6 +176,59 @@ cdef object _take_vectors(polycap_vector3 *p, size_t n):
         view[i, 0] = p[i].x; view[i, 1] = p[i].y; view[i, 2] = p[i].z
     polycap_free(p)
     return arr
+
+
+cdef class Leak:
+    """One leak event: where the transmitted fraction of a reflection left the optic (extleak) or reached the exit plane
+    inside the glass (intleak), with the per-energy weights it carried."""
+    cdef object _coords, _direction, _elecv, _weight
+    cdef int64_t _n_refl
+
+    @property
+    def coords(self):
+        return self._coords
+
+    @property
+    def direction(self):
+        return self._direction
+
+    @property
+    def elecv(self):
+        return self._elecv
+
+    @property
+    def weight(self):
+        return self._weight
+
+    @property
+    def n_refl(self):
+        return self._n_refl
+
+
+cdef object _take_leaks(polycap_leak **leaks, int64_t n):
+    """polycap_leak array of a getter -> list of Leak; the C structs are freed"""
+    out = []
+    cdef int64_t i
+    cdef size_t e
+    cdef Leak l
+    cdef double[::1] view
+    if leaks == NULL:
+        return out
+    for i in range(n):
+        l = Leak.__new__(Leak)
+        l._coords = _tuple(leaks[i].coords)
+        l._direction = _tuple(leaks[i].direction)
+        l._elecv = _tuple(leaks[i].elecv)
+        w = np.empty(leaks[i].n_energies, dtype=np.float64)
+        view = w
+        for e in range(leaks[i].n_energies):
+            view[e] = leaks[i].weight[e]
+        l._weight = w
+        l._n_refl = leaks[i].n_refl
+        out.append(l)
+        polycap_leak_free(leaks[i])
+    polycap_free(leaks)
+    return out
 
 
 cdef class Profile:
@@ -298,6 +365,31 @@ cdef class Photon:
     cdef polycap_photon *_photon
     cdef object _description
     cdef public int return_code
+    cdef object _leak_cache
+
+    def _leaks(self, int kind):
+        cdef polycap_error *error = NULL
+        cdef polycap_leak **arr = NULL
+        cdef int64_t n = 0
+        if self._leak_cache is None:
+            self._leak_cache = {}
+        if kind not in self._leak_cache:
+            if kind == 0:
+                polycap_photon_get_extleak_data(self._photon, &arr, &n, &error)
+            else:
+                polycap_photon_get_intleak_data(self._photon, &arr, &n, &error)
+            lst = _take_leaks(arr, n)
+            _raise_if(error)
+            self._leak_cache[kind] = lst
+        return self._leak_cache[kind]
+
+    @property
+    def extleak_data(self):
+        return (l for l in self._leaks(0))
+
+    @property
+    def intleak_data(self):
+        return (l for l in self._leaks(1))
 
     def __cinit__(self, Description description=None, object start_coords=None, object start_direction=None, object start_electric_vector=None):
         cdef polycap_error *error = NULL
@@ -321,6 +413,7 @@ cdef class Photon:
         cdef double *weights = NULL
         e = np.atleast_1d(np.ascontiguousarray(energies, dtype=np.float64))
         cdef double[::1] ev = e
+        self._leak_cache = None
         cdef int rc = polycap_photon_launch(self._photon, <size_t> e.shape[0], &ev[0], &weights, leak_calc, &error)
         out = _take_doubles(weights, e.shape[0]) if weights != NULL else None
         _raise_if(error)
@@ -367,6 +460,31 @@ cdef class TransmissionEfficiencies:
     cdef polycap_transmission_efficiencies *_eff
     cdef object _source
     cdef object _data
+    cdef object _leak_cache
+
+    def _leaks(self, int kind):
+        cdef polycap_error *error = NULL
+        cdef polycap_leak **arr = NULL
+        cdef int64_t n = 0
+        if self._leak_cache is None:
+            self._leak_cache = {}
+        if kind not in self._leak_cache:
+            if kind == 0:
+                polycap_transmission_efficiencies_get_extleak_data(self._eff, &arr, &n, &error)
+            else:
+                polycap_transmission_efficiencies_get_intleak_data(self._eff, &arr, &n, &error)
+            lst = _take_leaks(arr, n)
+            _raise_if(error)
+            self._leak_cache[kind] = lst
+        return self._leak_cache[kind]
+
+    @property
+    def extleak_data(self):
+        return (l for l in self._leaks(0))
+
+    @property
+    def intleak_data(self):
+        return (l for l in self._leaks(1))
 
     def __cinit__(self):
         self._eff = NULL

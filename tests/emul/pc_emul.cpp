@@ -103,17 +103,19 @@ int emul_launch_leak(const pc_hip_problem *p, int literal, int64_t n,
 	const int ne = (int)p->n_energies;
 	std::vector<double> frames((size_t)max_depth * (PC_LF_HDR + ne));
 	unsigned long long cursor = 0;
-	pc_leak_ctx cx;
+	pc_leak_lane L;
+	pc_leak_ctx &cx = L.cx;
+	pc_photon<0> &ph = L.ph;
 	cx.ec = E.t.ec.data(); cx.amu = E.t.amu.data(); cx.ne = ne;
 	cx.frames = frames.data(); cx.max_depth = max_depth;
 	cx.sink.records = records; cx.sink.cursor = &cursor; cx.sink.capacity = capacity;
 	cx.stack_overflow = 0;
 	for (int64_t j = 0; j < n; j++) {
 		const double *s = start + 3*j, *d = dir + 3*j, *e = elecv + 3*j;
-		pc_photon<0> ph; ph.wmem = nullptr; ph.wstride = 1;
+		ph.wmem = nullptr; ph.wstride = 1;
 		int st = pc_launch_init(E.T, E.t.pm, ph, s[0], s[1], s[2], d[0], d[1], d[2], e[0], e[1], e[2]);
 		cx.slot = (double)j; cx.attempt = 0.;
-		rc[j] = pc_leak_launch(E.T, E.t.pm, cx, ph, st, s[2]);
+		rc[j] = pc_leak_launch(E.T, E.t.pm, L, st, s[2]);
 		for (int k = 0; k < ne; k++) weights[(size_t)j*ne + k] = frames[PC_LF_HDR + k];
 		exit_coords[3*j] = ph.Px; exit_coords[3*j+1] = ph.Py; exit_coords[3*j+2] = ph.Pz;
 		exit_dir[3*j] = ph.dx; exit_dir[3*j+1] = ph.dy; exit_dir[3*j+2] = ph.dz;
@@ -138,7 +140,9 @@ int emul_transmission_leak(const pc_hip_problem *p, uint64_t seed, int64_t slot0
 	const int ne = (int)p->n_energies;
 	std::vector<double> frames((size_t)max_depth * (PC_LF_HDR + ne));
 	unsigned long long cursor = 0;
-	pc_leak_ctx cx;
+	pc_leak_lane L;
+	pc_leak_ctx &cx = L.cx;
+	pc_photon<0> &ph = L.ph;
 	cx.ec = E.t.ec.data(); cx.amu = E.t.amu.data(); cx.ne = ne;
 	cx.frames = frames.data(); cx.max_depth = max_depth;
 	cx.sink.records = records; cx.sink.cursor = &cursor; cx.sink.capacity = capacity;
@@ -150,10 +154,10 @@ int emul_transmission_leak(const pc_hip_problem *p, uint64_t seed, int64_t slot0
 			pc_start s;
 			if (E.t.pm.generic_src) pc_sample_photon<true>(E.t.pm, seed, (uint64_t)(slot0 + j), attempt, s);
 			else pc_sample_photon<false>(E.t.pm, seed, (uint64_t)(slot0 + j), attempt, s);
-			pc_photon<0> ph; ph.wmem = nullptr; ph.wstride = 1;
+			ph.wmem = nullptr; ph.wstride = 1;
 			int st = pc_launch_init(E.T, E.t.pm, ph, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez);
 			cx.slot = (double)(slot0 + j); cx.attempt = (double)attempt;
-			int rc = pc_leak_launch(E.T, E.t.pm, cx, ph, st, s.z);
+			int rc = pc_leak_launch(E.T, E.t.pm, L, st, s.z);
 			int ok = 0;
 			if (rc == 0) counters[2]++;
 			else if (rc == 2) counters[1]++;

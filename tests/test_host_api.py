@@ -110,8 +110,12 @@ def test_rng_and_photon_argument_checks(capi):
     assert ph.start_coords == (0, 0, 0) and ph.d_travel == 0 and ph.i_refl == 0
     with pytest.raises(ValueError, match="energies"):
         ph.launch([0.5])              # energy below 1 keV is rejected before any device work
-    with pytest.raises(NotImplementedError):
-        ph.launch([10.0], leak_calc=True)
+    import polycap_amd
+    if polycap_amd.device_count() == 0:
+        # no CPU trace path, with or without the leak calculation: the launch fails loudly
+        for leak in (False, True):
+            with pytest.raises(RuntimeError, match="HIP"):
+                ph.launch([10.0], leak_calc=leak)
 
 
 def test_source_new_and_from_file(capi, known):
@@ -133,8 +137,10 @@ def test_source_new_and_from_file(capi, known):
     src = capi.Source.new_from_file(os.path.join(EXAMPLE, "ellip_l9.inp"))
     with pytest.raises(ValueError, match="n_photons must be greater than 1"):
         src.get_transmission_efficiencies(-1, -1)
-    with pytest.raises(NotImplementedError):
-        src.get_transmission_efficiencies(1, 10, leak_calc=True)
+    import polycap_amd
+    if polycap_amd.device_count() == 0:
+        with pytest.raises(RuntimeError, match="HIP"):
+            src.get_transmission_efficiencies(1, 10, leak_calc=True)
 
 
 def test_inp_decks_and_open_area(known):
