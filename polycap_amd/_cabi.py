@@ -23,6 +23,11 @@ PC_HIP_ERR_ATTEMPTS = -5
 PC_HIP_LEAK_HDR = 12   # doubles before the weights of one leak event (include/polycap-hip.h)
 
 
+class ErrS(C.Structure):
+    """polycap_error (include/polycap.h); the one ctypes type every binding module uses for it"""
+    _fields_ = [("code", C.c_int), ("message", C.c_char_p)]
+
+
 class ProblemS(C.Structure):
     """struct pc_hip_problem"""
     _fields_ = [("nmax", C.c_int32), ("z", c_double_p), ("cap", c_double_p), ("ext", c_double_p),

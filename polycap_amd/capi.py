@@ -26,8 +26,7 @@ class _Leak(C.Structure):
                 ("weight", C.POINTER(C.c_double)), ("n_refl", C.c_int64)]
 
 
-class _Err(C.Structure):
-    _fields_ = [("code", C.c_int), ("message", C.c_char_p)]
+_Err = _cabi.ErrS
 
 
 _ErrP = C.POINTER(_Err)

@@ -6,10 +6,7 @@ import numpy as np
 
 from . import _cabi
 from ._cabi import Problem, ProblemS, c_double_p
-
-
-class _ErrS(C.Structure):
-    _fields_ = [("code", C.c_int), ("message", C.c_char_p)]
+from ._cabi import ErrS as _ErrS
 
 
 def _raise(L, err, where):
