@@ -62,8 +62,20 @@ def build(force=False, verbose=False):
         objs.append(obj)
     if force or _newer(LIB, objs):
         _run(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-lm"], verbose)
+    build_cli(force=force, verbose=verbose)
     build_cython(force=force, verbose=verbose)
     return LIB
+
+
+def build_cli(force=False, verbose=False):
+    """The `polycap` command-line program (reference src/main.c): polycap_amd/bin/polycap, rpath to ../lib."""
+    src = os.path.join(HOST, "pc_main.c")
+    exe = os.path.join(HERE, "bin", "polycap")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    if force or _newer(exe, [src, LIB]):
+        _run(["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-I" + INC, src, "-L" + LIBDIR, "-lpolycap",
+              "-Wl,-rpath,$ORIGIN/../lib", "-o", exe], verbose)
+    return exe
 
 
 def build_cython(force=False, verbose=False):

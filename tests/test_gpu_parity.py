@@ -357,3 +357,23 @@ def test_full_size_properties_xos1_1e7(pa):
     sig = 1.08 / np.sqrt(small["i_start"])
     assert abs(small["efficiencies"][0] - full["efficiencies"][0]) / full["efficiencies"][0] < 5 * sig
     assert 35.0 < full["sum_irefl"] / n < 42.0     # reflections per exit photon (SURVEY: 38.3-38.6)
+
+
+def test_command_line_program(pa, tmp_path):
+    """reference src/main.c: deck in, HDF5 result file out; fourth argument 1 switches the leak calculation on"""
+    import os
+    import subprocess
+    from tests.conftest import EXAMPLE, ROOT
+    from tests import test_hdf5_writer as H
+    exe = os.path.join(ROOT, "polycap_amd", "bin", "polycap")
+    out = str(tmp_path / "ellip.h5")
+    env = dict(os.environ, POLYCAP_SEED="7")
+    r = subprocess.run([exe, os.path.join(EXAMPLE, "ellip_l9.inp"), out, "4", "1", "2000"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "Starting calculations" in r.stdout and "iexit: 2000" in r.stdout
+    assert os.path.getsize(out) > 2000 * 17 * 8
+    if H.H5LS is not None:
+        shapes = H._listing(out)
+        assert shapes["/PC_Exit/Coordinates"] == (3, 2000) and "/Input/PC_Shape" in shapes
+        eff = H._read(out, "/Transmission_Efficiencies", str(tmp_path))
+        assert np.all((eff >= 0) & (eff <= 1)) and eff.max() > 0

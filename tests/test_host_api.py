@@ -172,3 +172,20 @@ def test_optical_constants_pin(known):
         polycap_amd.optical_constants([82], [1.0], 11.3, [10.0])
     with pytest.raises(ValueError, match="energies"):
         polycap_amd.optical_constants(g["iz"], g["wi_percent"], g["density"], [0.5])
+
+
+def test_command_line_program_without_gpu(tmp_path):
+    """reference src/main.c: usage line without arguments, message + status 1 for an unreadable deck; with a deck but
+    no GPU the run fails loudly (no CPU fallback)."""
+    import subprocess
+    import polycap_amd
+    from tests.conftest import ROOT
+    exe = os.path.join(ROOT, "polycap_amd", "bin", "polycap")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "input-file should be supplied" in r.stdout
+    r = subprocess.run([exe, str(tmp_path / "missing.inp")], capture_output=True, text=True)
+    assert r.returncode == 1 and "could not open" in r.stderr
+    if polycap_amd.device_count() == 0:
+        r = subprocess.run([exe, os.path.join(EXAMPLE, "cone.inp"), str(tmp_path / "out.h5")], capture_output=True, text=True)
+        assert r.returncode == 1 and "no HIP device" in r.stderr and not (tmp_path / "out.h5").exists()
