@@ -105,7 +105,8 @@ __device__ __forceinline__ void pc_atomic_add128(unsigned long long *lohi, unsig
 }
 
 /* --------------------------------------------------------------------------- the trace kernel
- * NE > 0: NE energies, weights in registers.  NE == 0: any n_energies, weights in wscratch.
+ * NE > 0: up to NE energies, weights in registers (NE = 1, 4, 8 are instantiated; a run with fewer energies than NE
+ * pads with copies of the last one whose weights are pinned to 0).  NE == 0: any n_energies, weights in wscratch.
  * MODE: PC_MODE_EXPLICIT: photons come from in_start/in_dir/in_elecv (polycap_photon_launch), no retry, no
  * source; PC_MODE_SRC_CIRCULAR / _GENERIC: photons are sampled from the source (circular / elliptical). */
 enum { PC_MODE_SRC_CIRCULAR = 0, PC_MODE_SRC_GENERIC = 1, PC_MODE_EXPLICIT = 2 };
@@ -131,7 +132,7 @@ pc_trace_kernel(pc_kargs a)
 		l_idz[k] = a.g_idz[k];
 		ldsf[k] = a.g_mb1[k]; ldsf[PITCH + k] = a.g_md1[k]; ldsf[2*PITCH + k] = a.g_mb2[k]; ldsf[3*PITCH + k] = a.g_md2[k];
 	}
-	if (NE == 0 && a.lds_acc)
+	if (NE != 1 && a.lds_acc)
 		for (int k = threadIdx.x; k < 2*a.pm.n_energies; k += blockDim.x) l_acc[k] = 0ull;
 	__syncthreads();
 	pc_tables T;
@@ -140,6 +141,7 @@ pc_trace_kernel(pc_kargs a)
 	const long long rec = PC_N_FIELDS + (long long)a.pm.n_energies;   /* doubles per image record */
 	const pc_params &Pm = a.pm;
 	const int ne = (NE > 0) ? NE : Pm.n_energies;
+	const int ner = Pm.n_energies;   /* NE > 1 serves any n_energies <= NE: the surplus weights start at 0 and stay there */
 	const int lane = threadIdx.x & (PC_WAVE - 1);
 	const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 
@@ -161,9 +163,7 @@ pc_trace_kernel(pc_kargs a)
 	/* per-lane totals */
 	/* 32 bits per lane are plenty (a lane handles n_slots / total_threads slots); the wave sums are 64-bit */
 	unsigned int n_exit = 0, n_not_entered = 0, n_not_trans = 0, s_irefl = 0, n_failed = 0, n_launch = 0;
-	unsigned long long acc_lo[NE > 0 ? NE : 1], acc_hi[NE > 0 ? NE : 1];
-#pragma unroll
-	for (int e = 0; e < (NE > 0 ? NE : 1); e++) { acc_lo[e] = 0; acc_hi[e] = 0; }
+	unsigned long long acc_lo[1] = {0}, acc_hi[1] = {0};   /* NE == 1: per-lane exact sum; NE > 1 and NE == 0 sum in LDS */
 
 	/* wave-uniform scheduler statistics (diagnostics: lane utilisation per phase type) */
 	unsigned long long st_march = 0, st_march_l = 0, st_event = 0, st_event_l = 0, st_new = 0, st_new_l = 0;
@@ -272,9 +272,11 @@ pc_trace_kernel(pc_kargs a)
 				if (EXPLICIT) {
 					const long long j = slot;
 					a.out_rc[j] = rc;
-					if (NE > 0)
-						for (int e = 0; e < ne; e++) a.out_weights[j*ne + e] = ph.w[NE > 0 ? e : 0];
-					else
+					if (NE > 0) {
+#pragma unroll
+						for (int e = 0; e < (NE > 0 ? NE : 1); e++)
+							if (e < ner) a.out_weights[j*ner + e] = ph.w[NE > 0 ? e : 0];
+					} else
 						coop = 1;    /* weights are copied by the cooperative sweep below */
 					a.out_exit_coords[3*j] = ph.Px; a.out_exit_coords[3*j+1] = ph.Py; a.out_exit_coords[3*j+2] = ph.Pz;
 					a.out_exit_dir[3*j] = ph.dx; a.out_exit_dir[3*j+1] = ph.dy; a.out_exit_dir[3*j+2] = ph.dz;
@@ -291,14 +293,24 @@ pc_trace_kernel(pc_kargs a)
 					if (ok) {
 						n_exit++;
 						s_irefl += (unsigned int)ph.irefl;
-						if (NE > 0) {
-							for (int e = 0; e < ne; e++) {
-								double w = ph.w[NE > 0 ? e : 0];
-								unsigned long long f = (unsigned long long)(w * PC_FIX_SCALE);
-								unsigned long long old = acc_lo[NE > 0 ? e : 0];
-								acc_lo[NE > 0 ? e : 0] = old + f;
-								acc_hi[NE > 0 ? e : 0] += (old + f < old) ? 1ull : 0ull;
-								if (a.keep_images) a.img[slot*rec + PC_F_WEIGHTS + e] = w;
+						if (NE == 1) {
+							double w = ph.w[0];
+							unsigned long long f = (unsigned long long)(w * PC_FIX_SCALE);
+							unsigned long long old = acc_lo[0];
+							acc_lo[0] = old + f;
+							acc_hi[0] += (old + f < old) ? 1ull : 0ull;
+							if (a.keep_images) a.img[slot*rec + PC_F_WEIGHTS] = w;
+						} else if (NE > 1) {
+							/* a few energies: exact sums in LDS (2 x u64 per energy), flushed once per workgroup */
+#pragma unroll
+							for (int e = 0; e < (NE > 0 ? NE : 1); e++) {
+								if (e < ner) {
+									double w = ph.w[NE > 0 ? e : 0];
+									unsigned long long f = (unsigned long long)(w * PC_FIX_SCALE);
+									unsigned long long old = atomicAdd(&l_acc[2*e], f);
+									if (old + f < old) atomicAdd(&l_acc[2*e + 1], 1ull);
+									if (a.keep_images) a.img[slot*rec + PC_F_WEIGHTS + e] = w;
+								}
 							}
 						} else {
 							coop = 1;    /* sums and image weights are handled by the cooperative sweep below */
@@ -324,7 +336,7 @@ pc_trace_kernel(pc_kargs a)
 						if (attempt >= a.max_attempts) {
 							n_failed++;
 							if (a.keep_images) {
-								if (NE > 0) for (int e = 0; e < ne; e++) a.img[slot*rec + PC_F_WEIGHTS + e] = 0.;
+								if (NE > 0) for (int e = 0; e < ner; e++) a.img[slot*rec + PC_F_WEIGHTS + e] = 0.;
 								else coop = 2;   /* zero weights */
 							}
 							state = LS_NEED_SLOT;
@@ -400,10 +412,18 @@ pc_trace_kernel(pc_kargs a)
 					state = pc_launch_init(T, Pm, ph, a.in_start[3*j], a.in_start[3*j+1], a.in_start[3*j+2],
 					                       a.in_dir[3*j], a.in_dir[3*j+1], a.in_dir[3*j+2],
 					                       a.in_elecv[3*j], a.in_elecv[3*j+1], a.in_elecv[3*j+2]);
+					if (NE > 1) {
+#pragma unroll
+						for (int e = 0; e < (NE > 0 ? NE : 1); e++) if (e >= ner) ph.w[NE > 0 ? e : 0] = 0.;
+					}
 				} else {
 					pc_start s;
 					pc_sample_photon<MODE == PC_MODE_SRC_GENERIC>(Pm, a.seed, (unsigned long long)(a.slot0 + slot), attempt, s);
 					state = pc_launch_init(T, Pm, ph, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez);
+					if (NE > 1) {
+#pragma unroll
+						for (int e = 0; e < (NE > 0 ? NE : 1); e++) if (e >= ner) ph.w[NE > 0 ? e : 0] = 0.;
+					}
 					if (state == LS_MARCH) {
 						/* src/polycap-source.c:779-798: start images of the attempt that is now inside a capillary;
 						 * the slot belongs to this lane, so a later (transmitted) attempt simply overwrites them */
@@ -424,7 +444,7 @@ pc_trace_kernel(pc_kargs a)
 		}
 	}
 
-	if (NE == 0 && !EXPLICIT && a.lds_acc) {
+	if (NE != 1 && !EXPLICIT && a.lds_acc) {
 		__syncthreads();          /* every wave of the workgroup has finished its photons */
 		for (int e = threadIdx.x; e < a.pm.n_energies; e += blockDim.x)
 			if (l_acc[2*e] | l_acc[2*e + 1]) pc_atomic_add128(a.sumw + 2*e, l_acc[2*e], l_acc[2*e + 1]);
@@ -444,9 +464,9 @@ pc_trace_kernel(pc_kargs a)
 			atomicAdd(&a.totals->phase[2], st_event); atomicAdd(&a.totals->phase[3], st_event_l);
 			atomicAdd(&a.totals->phase[4], st_new); atomicAdd(&a.totals->phase[5], st_new_l);
 		}
-		if (NE > 0) {
+		if (NE == 1) {
 #pragma unroll
-			for (int e = 0; e < (NE > 0 ? NE : 1); e++) {
+			for (int e = 0; e < 1; e++) {
 				/* exact wave sum of 128-bit values through three 64-bit partial sums */
 				unsigned long long s_hi = pc_wave_sum_u64(acc_hi[e]);
 				unsigned long long s_mid = pc_wave_sum_u64(acc_lo[e] >> 32);
@@ -577,11 +597,13 @@ template <int NE, int MODE>
 static int pc_launch_one(pc_hip_ctx *ctx, const pc_kargs &a, int grid)
 {
 	/* table pitch: 1024 entries (48 KB of LDS) covers the reference's generated profiles (nmax = 999) and its example decks */
-	const size_t dyn = (NE == 0 && a.lds_acc) ? 2*(size_t)ctx->host.pm.n_energies*sizeof(unsigned long long) : 0;
+	const size_t dyn = (NE != 1 && a.lds_acc) ? 2*(size_t)ctx->host.pm.n_energies*sizeof(unsigned long long) : 0;
 	if (ctx->host.pm.nmax + 1 <= 1024)
 		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, 1024>), dim3(grid), dim3(ctx->block_size), dyn, ctx->stream, a);
+	else if (NE <= 1)   /* long profiles: only the NE = 1 and the any-n_energies kernels are built for the 2048 pitch */
+		hipLaunchKernelGGL((pc_trace_kernel<(NE <= 1 ? NE : 0), MODE, PC_MAX_PITCH>), dim3(grid), dim3(ctx->block_size), dyn, ctx->stream, a);
 	else
-		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, PC_MAX_PITCH>), dim3(grid), dim3(ctx->block_size), dyn, ctx->stream, a);
+		return pc_fail(PC_HIP_ERR_INVALID, "internal: register-weight kernels are built for profiles of up to 1024 points");
 	PC_HIP_CHECK(hipGetLastError());
 	return PC_HIP_OK;
 }
@@ -596,8 +618,10 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 	int grid = (int)(want_blocks < max_blocks ? want_blocks : max_blocks);
 	if (grid < 1) grid = 1;
 	a.total_threads = (long long)grid * block;
+	/* weights in registers for up to 8 energies (kernels NE = 1, 4, 8), in the per-lane scratch beyond */
+	const int kne = (ne == 1) ? 1 : ((ne <= 4 && ctx->host.pm.nmax + 1 <= 1024) ? 4 : ((ne <= 8 && ctx->host.pm.nmax + 1 <= 1024) ? 8 : 0));
 	a.lds_acc = (ne != 1 && 2*(size_t)ne*sizeof(unsigned long long) <= 16384) ? 1 : 0;
-	if (ne != 1) {
+	if (kne == 0) {
 		size_t need = (size_t)ne * (size_t)a.total_threads;
 		if (need > ctx->wscratch_elems) {
 			if (ctx->d_wscratch) PC_HIP_CHECK(hipFree(ctx->d_wscratch));
@@ -609,7 +633,8 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		a.wscratch = ctx->d_wscratch;
 	}
 	PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
-	int st = (ne == 1) ? pc_launch_one<1, MODE>(ctx, a, grid) : pc_launch_one<0, MODE>(ctx, a, grid);
+	int st = (kne == 1) ? pc_launch_one<1, MODE>(ctx, a, grid) : (kne == 4) ? pc_launch_one<4, MODE>(ctx, a, grid)
+	       : (kne == 8) ? pc_launch_one<8, MODE>(ctx, a, grid) : pc_launch_one<0, MODE>(ctx, a, grid);
 	if (st) return st;
 	PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
 	return PC_HIP_OK;
@@ -687,8 +712,13 @@ int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ou
 	const std::vector<float> *fsrc[4] = { &ctx->host.mb1, &ctx->host.md1, &ctx->host.mb2, &ctx->host.md2 };
 	for (int k = 0; k < 4; k++)
 		PC_CTX_CHECK(hipMemcpy(ctx->d_ftables + k*npts, fsrc[k]->data(), npts*sizeof(float), hipMemcpyHostToDevice));
-	PC_CTX_CHECK(hipMalloc(&ctx->d_ec, ctx->host.ec.size()*sizeof(pc_energy_const)));
-	PC_CTX_CHECK(hipMemcpy(ctx->d_ec, ctx->host.ec.data(), ctx->host.ec.size()*sizeof(pc_energy_const), hipMemcpyHostToDevice));
+	{
+		/* at least 8 entries: the register-weight kernels read NE constants whatever n_energies is (surplus = copies of the last) */
+		std::vector<pc_energy_const> ecp(ctx->host.ec);
+		while (ecp.size() < 8) ecp.push_back(ecp.back());
+		PC_CTX_CHECK(hipMalloc(&ctx->d_ec, ecp.size()*sizeof(pc_energy_const)));
+		PC_CTX_CHECK(hipMemcpy(ctx->d_ec, ecp.data(), ecp.size()*sizeof(pc_energy_const), hipMemcpyHostToDevice));
+	}
 	{
 		const size_t ne = ctx->host.ec.size();
 		std::vector<double> soa(6*ne);
