@@ -218,6 +218,7 @@ enum {
 
 struct pc_wall {
 	int z_id, seg_step, seg_slope, cool, iesc, wt;
+	int units;                         /* units of work spent on this search (guard against a search that cannot end) */
 	long long nst;
 	double q_i, r_i, q_new, r_new;
 	double px, py, pz;                 /* point reached by the stepping */
@@ -342,7 +343,7 @@ PC_HD int pc_wall_begin(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 	W.hx = ph.Px; W.hy = ph.Py; W.hz = ph.Pz;
 	W.dist = 0.; W.base = 0.; W.nst = 0; W.step = 0.;
 	W.seg_step = -1; W.seg_slope = -1; W.cool = 0;
-	W.iesc = 0;
+	W.iesc = 0; W.units = 0;
 	return Pm.mono ? PC_LS_WALL_PROBE : PC_LS_WALL_STEP;
 }
 
@@ -356,6 +357,10 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 	const double Px = ph.Px, Py = ph.Py, Pz = ph.Pz, dx = ph.dx, dy = ph.dy, dz = ph.dz;
 	int z_id = W.z_id;
 
+	/* A search that has not ended after 2^28 units cannot end (e.g. a direction without z component inside a cell that
+	 * never changes; the reference would loop forever): the reflection is reported as failed (launch returns -1). */
+	if (++W.units > (1 << 28)) { W.wt = -3; return after; }
+
 	/* ---- certified skipping.  Inside one profile segment the point relative to the centre of cell (q_i, r_i),
 	 * u = p - K*zz(z), moves on a straight line while the cell hexagon (inradius zz*sqrt(3)/2) and the capillary circle
 	 * (radius rad0) change linearly.  |n.u| - h is convex along the block, so the hexagon tests hold inside the block if
@@ -365,8 +370,16 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 	if (!Pm.literal && W.cool == 0 && dz > 0. && T.z[z_id] <= W.pz && W.pz < T.z[z_id+1]) {
 		const double stp = T.cap[z_id]/10.;
 		const double room = (T.z[z_id+1] - W.pz)/(stp*dz);
-		int m = (room > 1.e6) ? 1000000 : (int)room - 2;
-		if (m >= 8) {
+		/* the block may run up to the last step that still lands inside this segment: the candidate count from the
+		 * division is checked against the position the literal arithmetic would produce there */
+		int m = (room > 1.e6) ? 1000000 : (int)room;
+		if (m >= 2) {
+			const long long n0 = (z_id != W.seg_step) ? 0 : W.nst;
+			const double b0 = (z_id != W.seg_step) ? W.dist : W.base;
+			if (!(Pz + (b0 + (double)(n0 + m)*stp)*dz < T.z[z_id+1])) m--;
+			if (!(Pz + (b0 + (double)(n0 + m)*stp)*dz < T.z[z_id+1])) m--;
+		}
+		if (m >= 2) {
 			const double es = (T.ext[z_id+1] - T.ext[z_id])/(T.z[z_id+1] - T.z[z_id]);
 			const double cs = (T.cap[z_id+1] - T.cap[z_id])/(T.z[z_id+1] - T.z[z_id]);
 			const int inside_stack = (fabs(W.q_i) <= ns && fabs(W.r_i) <= ns && fabs(-1.*W.q_i-W.r_i) <= ns);
@@ -378,7 +391,7 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 			const double vx = dx - Kx*dzz, vy = dy - Ky*dzz;
 			const double margin = 1.e-6 * zz0;
 			int ok = 0;
-			for (; m >= 8; m >>= 2) {
+			for (; m >= 2; m >>= 2) {
 				const double D = (double)m * stp * (1. + 1.e-9);
 				const double u1x = u0x + vx*D, u1y = u0y + vy*D;
 				const double h0 = PC_COSPI_6*zz0 - margin, h1 = PC_COSPI_6*(zz0 + dzz*D) - margin;
@@ -405,7 +418,7 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 				W.pz = Pz + W.dist*dz;
 				return PC_LS_WALL_STEP;
 			}
-			W.cool = 8;
+			W.cool = 1;      /* a failed certificate means a cell edge or the capillary is within a step or two: one literal step, then try again */
 		}
 	}
 	if (W.cool > 0) W.cool--;
@@ -464,9 +477,50 @@ PC_HD int pc_wall_probe(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 	pc_photon<0> probe = L.ph;          /* same ray, other capillary axis */
 	if (Pm.mono) { probe.kx = 0.; probe.ky = 0.; }
 	else { probe.ky = W.r_new * (3./2); probe.kx = (2.* W.q_new+W.r_new) * PC_COSPI_6; }
-	double p0x, p0y, nx, ny, nz;
-	W.iesc = pc_segment(T, probe, W.z_id, p0x, p0y, W.hx, W.hy, W.hz, nx, ny, nz);
-	W.z_id++;
+	/* ---- certain misses.  Relative to the axis of the probed capillary the ray is q(z) = p(z) - K*zh(z).  Over L segments
+	 * q stays within kn*md_L of the chord between its two end values (md_L: tabulated chord deviation of zh, 0 for L = 1)
+	 * and the radius never exceeds Rmax, so when the chord's closest approach to the axis is farther than
+	 * Rmax + kn*md_L (+ margin) the ray is outside the capillary on all L segments: the reference's quadratic
+	 * (src/polycap-capil.c:119-171) has no root inside any of them and every one of the L visits is a miss. */
+	int skipped = 0;
+	if (!Pm.literal) {
+		const int i0 = W.z_id;
+		const double kn = sqrt(probe.kx*probe.kx + probe.ky*probe.ky);
+		const double z0 = T.z[i0], zh0 = T.zh[i0];
+		const double ax = fma(-probe.kx, zh0, fma(probe.sx, z0, probe.ox));
+		const double ay = fma(-probe.ky, zh0, fma(probe.sy, z0, probe.oy));
+		for (int lv = 2; lv >= 0 && !skipped; lv--) {
+			const int Ls = (lv == 2) ? PC_L2 : ((lv == 1) ? PC_L1 : 1);
+			if (Ls > 1 && i0 + Ls > nmax-1) continue;      /* the literal loop stops before segment nmax-1 */
+			const int i1 = i0 + Ls;
+			const double z1 = T.z[i1], zh1 = T.zh[i1];
+			const double bx = fma(-probe.kx, zh1, fma(probe.sx, z1, probe.ox));
+			const double by = fma(-probe.ky, zh1, fma(probe.sy, z1, probe.oy));
+			const double ex = bx - ax, ey = by - ay;
+			const double ee = ex*ex + ey*ey;
+			double t = (ee > 0.) ? -(ax*ex + ay*ey)/ee : 0.;
+			t = (t < 0.) ? 0. : ((t > 1.) ? 1. : t);
+			const double cxm = ax + t*ex, cym = ay + t*ey;
+			double reach;
+			if (Ls == 1) {
+				const double r0 = T.cap[i0], r1 = T.cap[i1];
+				reach = (r0 > r1) ? r0 : r1;
+			} else {
+				reach = 0.5*Pm.two_rmax + kn * (double)((lv == 2) ? T.md2[i0] : T.md1[i0]);
+			}
+			reach += 1.e-7 * (0.5*Pm.two_rmax);
+			if (cxm*cxm + cym*cym > reach*reach) {
+				W.z_id = i1;
+				W.iesc = -3;
+				skipped = 1;
+			}
+		}
+	}
+	if (!skipped) {
+		double p0x, p0y, nx, ny, nz;
+		W.iesc = pc_segment(T, probe, W.z_id, p0x, p0y, W.hx, W.hy, W.hz, nx, ny, nz);
+		W.z_id++;
+	}
 	if (W.iesc != 1 && W.z_id < nmax-1)
 		return PC_LS_WALL_PROBE;
 	if (!Pm.mono && W.z_id >= nmax && W.iesc != 0) {

@@ -25,5 +25,10 @@ for E in ([10.0], [1., 5., 10., 15., 20., 25., 30.]):
             t0 = time.perf_counter()
             r = ctx.transmission(20000, 0, n, leak_calc=True)
             dt = time.perf_counter() - t0
+            st = ctx.phase_stats()      # leak runs: the three pairs are wall steps, capillary probes, march steps
+            util = "lanes/unit: wall %.1f probe %.1f march %.1f; units %.3g %.3g %.3g" % (
+                st["march"]["avg_lanes"], st["event"]["avg_lanes"], st["new"]["avg_lanes"],
+                st["march"]["phases"], st["event"]["phases"], st["new"]["phases"])
             print("nE=%d slots=%6d kernel %9.1f ms wall %7.2f s  started %7d  ext %7d int %7d  -> %.3g started photons/s" %
                   (len(E), n, r["kernel_ms"], dt, r["i_start"], len(r["ext"]), len(r["int"]), r["i_start"] / (r["kernel_ms"] * 1e-3)), flush=True)
+            print("      " + util, flush=True)
