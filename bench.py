@@ -28,7 +28,7 @@ import numpy as np
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this same command, condensed by scripts/summarize_profile.py
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "v5_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "v7_pmc_summary.json")
 
 
 def measured_traffic(n_local, keep_images):
@@ -55,7 +55,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20000)
     ap.add_argument("--no-images", action="store_true", help="histogram-only mode (no per-photon planes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=400_000, help="exit-photon slots of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="exit-photon slots of the CPU baseline sample (0 = sized from a short probe to about 15 s of CPU work)")
     ap.add_argument("--opt", action="append", default=[], help="kernel option name=value (event_threshold, blocks_per_cu, ...)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-process "
@@ -205,10 +206,17 @@ def cpu_baseline(prob, args, ctx):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    n = args.cpu_sample
     optic = O.Optic(prob.z, prob.cap, prob.ext, prob.sig_rough, prob.n_cap, prob.density)
     src = O.make_source(*prob.source)
     O.transmission(optic, src, prob.energies, prob.amu, prob.scatf, args.seed, 0, 2000, n_threads=cores)  # warm up
+    n = args.cpu_sample
+    if n <= 0:
+        # bounded sample: a probe sets the size so that the timed run is about 15 s on this host's cores
+        probe = 2000 * cores
+        t0 = time.perf_counter()
+        O.transmission(optic, src, prob.energies, prob.amu, prob.scatf, args.seed, 0, probe, n_threads=cores)
+        rate = probe / max(time.perf_counter() - t0, 1e-3)
+        n = int(min(max(15.0 * rate, 50_000), 8_000_000))
     t0 = time.perf_counter()
     o = O.transmission(optic, src, prob.energies, prob.amu, prob.scatf, args.seed, 0, n, n_threads=cores)
     dt = time.perf_counter() - t0
