@@ -347,6 +347,40 @@ PC_HD int pc_wall_begin(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 	return Pm.mono ? PC_LS_WALL_PROBE : PC_LS_WALL_STEP;
 }
 
+#ifndef PC_WALL_HOPS
+#define PC_WALL_HOPS 1     /* profile segments one unit of the wall search may cross; measured on MI355X (scripts/ab_leak.sh): 1 -> 515 ms, 2 -> 558, 4 -> 606, 8 -> 630 for 262144 slots: longer units diverge more inside the wave than they save */
+#endif
+
+/* Certificate for one straight piece of the wall search inside ONE profile segment (tables linear): from (x0, y0) at
+ * height zrel0 above the segment's first node, along the direction (dx, dy, dz), path length D.  seg_ext/es and seg_cap/cs
+ * are the segment's ext and cap at its first node and their slopes.  Returns 1 when no point of the piece can leave the
+ * cell hexagon of centre K*zz or enter the capillary circle (margin 1e-6 of the cell size), 0 when that cannot be
+ * shown, -1 when already the start point is within the margin. */
+PC_HD int pc_wall_piece_safe(const pc_params &Pm, double Kx, double Ky, int inside_stack, double x0, double y0, double zrel0,
+                             double dx, double dy, double dz, double D, double seg_ext, double es, double seg_cap, double cs)
+{
+	const double zz0 = (es * zrel0 + seg_ext) / Pm.hexscale;
+	const double dzz = es * dz / Pm.hexscale;                 /* d zz / d path */
+	const double r00 = cs * zrel0 + seg_cap;
+	const double u0x = x0 - Kx*zz0, u0y = y0 - Ky*zz0;
+	const double vx = dx - Kx*dzz, vy = dy - Ky*dzz;
+	const double margin = 1.e-6 * zz0;
+	const double u1x = u0x + vx*D, u1y = u0y + vy*D;
+	const double h0 = PC_COSPI_6*zz0 - margin, h1 = PC_COSPI_6*(zz0 + dzz*D) - margin;
+	if (fabs(u0x) > h0 || fabs(0.5*u0x + PC_COSPI_6*u0y) > h0 || fabs(0.5*u0x - PC_COSPI_6*u0y) > h0) return -1;
+	if (fabs(u1x) > h1 || fabs(0.5*u1x + PC_COSPI_6*u1y) > h1 || fabs(0.5*u1x - PC_COSPI_6*u1y) > h1) return 0;
+	if (inside_stack) {
+		const double vv = vx*vx + vy*vy;
+		double ts = (vv > 0.) ? -(u0x*vx + u0y*vy)/vv : 0.;
+		ts = (ts < 0.) ? 0. : ((ts > D) ? D : ts);
+		const double cxm = u0x + vx*ts, cym = u0y + vy*ts;
+		const double r1 = r00 + cs*dz*D;
+		const double rmax = ((r00 > r1) ? r00 : r1) + margin;
+		if (cxm*cxm + cym*cym < rmax*rmax) return 0;
+	}
+	return 1;
+}
+
 /* one unit of the stepping loop (:1016-1064): either one certified block of steps, or one literal step with its tests */
 PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L, int after)
 {
@@ -363,63 +397,74 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 
 	/* ---- certified skipping.  Inside one profile segment the point relative to the centre of cell (q_i, r_i),
 	 * u = p - K*zz(z), moves on a straight line while the cell hexagon (inradius zz*sqrt(3)/2) and the capillary circle
-	 * (radius rad0) change linearly.  |n.u| - h is convex along the block, so the hexagon tests hold inside the block if
-	 * they hold at both ends; the circle test holds if the closest approach of the line to the centre stays outside the
-	 * larger of the two end radii.  With a margin far above rounding (1e-6 of the cell size) none of the next m literal
-	 * steps can leave the loop, so only their effect on `dist` is carried out. */
-	if (!Pm.literal && W.cool == 0 && dz > 0. && T.z[z_id] <= W.pz && W.pz < T.z[z_id+1]) {
-		const double stp = T.cap[z_id]/10.;
-		const double room = (T.z[z_id+1] - W.pz)/(stp*dz);
-		/* the block may run up to the last step that still lands inside this segment: the candidate count from the
-		 * division is checked against the position the literal arithmetic would produce there */
-		int m = (room > 1.e6) ? 1000000 : (int)room;
-		if (m >= 2) {
+	 * (radius rad0) change linearly.  |n.u| - h is convex along such a piece, so the hexagon tests hold on it if they hold
+	 * at both ends; the circle test holds if the closest approach of the line to the centre stays outside the larger of
+	 * the two end radii (pc_wall_piece_safe, margin 1e-6 of the cell size, far above rounding).  None of the literal
+	 * steps that land on a safe piece can leave the loop, so only their effect on `dist` is carried out: a block runs to
+	 * the last step inside the segment, and the step that crosses into the next segment is taken along with it when the
+	 * two short pieces up to the node and from the node to the landing point are safe too -- then the next segment follows
+	 * in the same unit. */
+	if (!Pm.literal && W.cool == 0 && dz > 0.) {
+		const int inside_stack = (fabs(W.q_i) <= ns && fabs(W.r_i) <= ns && fabs(-1.*W.q_i-W.r_i) <= ns);
+		const double Kx = (2.*W.q_i + W.r_i) * PC_COSPI_6, Ky = W.r_i * 1.5;
+		int advanced = 0;
+		for (int hop = 0; hop < PC_WALL_HOPS; hop++) {
+			if (!(T.z[z_id] <= W.pz && W.pz < T.z[z_id+1])) break;
+			const double stp = T.cap[z_id]/10.;
+			const double room = (T.z[z_id+1] - W.pz)/(stp*dz);
+			/* the block may run up to the last step that still lands inside this segment: the candidate count from the
+			 * division is checked against the position the literal arithmetic would produce there */
+			int m = (room > 1.e6) ? 1000000 : (int)room;
 			const long long n0 = (z_id != W.seg_step) ? 0 : W.nst;
 			const double b0 = (z_id != W.seg_step) ? W.dist : W.base;
-			if (!(Pz + (b0 + (double)(n0 + m)*stp)*dz < T.z[z_id+1])) m--;
-			if (!(Pz + (b0 + (double)(n0 + m)*stp)*dz < T.z[z_id+1])) m--;
-		}
-		if (m >= 2) {
-			const double es = (T.ext[z_id+1] - T.ext[z_id])/(T.z[z_id+1] - T.z[z_id]);
-			const double cs = (T.cap[z_id+1] - T.cap[z_id])/(T.z[z_id+1] - T.z[z_id]);
-			const int inside_stack = (fabs(W.q_i) <= ns && fabs(W.r_i) <= ns && fabs(-1.*W.q_i-W.r_i) <= ns);
-			const double Kx = (2.*W.q_i + W.r_i) * PC_COSPI_6, Ky = W.r_i * 1.5;
-			const double zz0 = (es * (W.pz - T.z[z_id]) + T.ext[z_id]) / Pm.hexscale;
-			const double dzz = es * dz / Pm.hexscale;                 /* d zz / d dist */
-			const double r00 = cs * (W.pz - T.z[z_id]) + T.cap[z_id];
-			const double u0x = W.px - Kx*zz0, u0y = W.py - Ky*zz0;
-			const double vx = dx - Kx*dzz, vy = dy - Ky*dzz;
-			const double margin = 1.e-6 * zz0;
-			int ok = 0;
-			for (; m >= 2; m >>= 2) {
+			if (m >= 1 && !(Pz + (b0 + (double)(n0 + m)*stp)*dz < T.z[z_id+1])) m--;
+			if (m >= 1 && !(Pz + (b0 + (double)(n0 + m)*stp)*dz < T.z[z_id+1])) m--;
+			const int m_full = m;
+			const double dzs = T.z[z_id+1] - T.z[z_id];
+			const double es = (T.ext[z_id+1] - T.ext[z_id])/dzs, cs = (T.cap[z_id+1] - T.cap[z_id])/dzs;
+			int ok = (m == 0);                 /* nothing left inside this segment: only the crossing step remains */
+			for (; m >= 2 && !ok; m = (m == m_full && hop > 0) ? 0 : (m >> 2)) {
 				const double D = (double)m * stp * (1. + 1.e-9);
-				const double u1x = u0x + vx*D, u1y = u0y + vy*D;
-				const double h0 = PC_COSPI_6*zz0 - margin, h1 = PC_COSPI_6*(zz0 + dzz*D) - margin;
-				if (fabs(u0x) > h0 || fabs(0.5*u0x + PC_COSPI_6*u0y) > h0 || fabs(0.5*u0x - PC_COSPI_6*u0y) > h0) break;
-				if (fabs(u1x) > h1 || fabs(0.5*u1x + PC_COSPI_6*u1y) > h1 || fabs(0.5*u1x - PC_COSPI_6*u1y) > h1) continue;
-				if (inside_stack) {
-					const double vv = vx*vx + vy*vy;
-					double ts = (vv > 0.) ? -(u0x*vx + u0y*vy)/vv : 0.;
-					ts = (ts < 0.) ? 0. : ((ts > D) ? D : ts);
-					const double cxm = u0x + vx*ts, cym = u0y + vy*ts;
-					const double r1 = r00 + cs*dz*D;
-					const double rmax = ((r00 > r1) ? r00 : r1) + margin;
-					if (cxm*cxm + cym*cym < rmax*rmax) continue;
-				}
-				ok = 1;
-				break;
+				const int r = pc_wall_piece_safe(Pm, Kx, Ky, inside_stack, W.px, W.py, W.pz - T.z[z_id], dx, dy, dz, D, T.ext[z_id], es, T.cap[z_id], cs);
+				if (r < 0) break;                /* the start point itself is within the margin */
+				if (r > 0) { ok = 1; break; }
 			}
-			if (ok) {
+			if (!ok || (m < 2 && m != 0)) break;
+			if (m > 0) {
 				if (z_id != W.seg_step) { W.seg_step = z_id; W.step = stp; W.base = W.dist; W.nst = 0; }
 				W.nst += m;
 				W.dist = W.base + (double)W.nst*W.step;
 				W.px = Px + W.dist*dx;
 				W.py = Py + W.dist*dy;
 				W.pz = Pz + W.dist*dz;
-				return PC_LS_WALL_STEP;
+				advanced = 1;
 			}
-			W.cool = 1;      /* a failed certificate means a cell edge or the capillary is within a step or two: one literal step, then try again */
+			if (m != m_full || z_id + 1 >= nmax) break;       /* a shortened block, or the last segment: no crossing here */
+			/* ---- the crossing step: from the last point inside the segment over the node to the landing point */
+			const long long n1 = (z_id != W.seg_step) ? 0 : W.nst;
+			const double b1 = (z_id != W.seg_step) ? W.dist : W.base;
+			const double qd = b1 + (double)(n1 + 1)*stp;
+			const double qx = Px + qd*dx, qy = Py + qd*dy, qz = Pz + qd*dz;
+			if (!(T.z[z_id+1] <= qz && qz < T.z[z_id+2])) break;
+			const double tB = (T.z[z_id+1] - W.pz)/dz * (1. + 1.e-9);            /* path length to the node */
+			if (pc_wall_piece_safe(Pm, Kx, Ky, inside_stack, W.px, W.py, W.pz - T.z[z_id], dx, dy, dz, tB, T.ext[z_id], es, T.cap[z_id], cs) <= 0) break;
+			const double dzn = T.z[z_id+2] - T.z[z_id+1];
+			const double esn = (T.ext[z_id+2] - T.ext[z_id+1])/dzn, csn = (T.cap[z_id+2] - T.cap[z_id+1])/dzn;
+			const double bx = Px + (W.dist + tB)*dx, by = Py + (W.dist + tB)*dy;     /* the ray at (just past) the node */
+			const double tQ = (qd - W.dist - tB);
+			if (tQ > 0. && pc_wall_piece_safe(Pm, Kx, Ky, inside_stack, bx, by, 0., dx, dy, dz, tQ * (1. + 1.e-9) + 1.e-12*stp, T.ext[z_id+1], esn, T.cap[z_id+1], csn) <= 0) break;
+			if (z_id != W.seg_step) { W.seg_step = z_id; W.step = stp; W.base = W.dist; W.nst = 0; }
+			W.nst += 1;
+			W.dist = W.base + (double)W.nst*W.step;
+			W.px = Px + W.dist*dx;
+			W.py = Py + W.dist*dy;
+			W.pz = Pz + W.dist*dz;
+			z_id = pc_node_follow(T, nmax, z_id, W.pz);
+			W.z_id = z_id;
+			advanced = 1;
 		}
+		if (advanced) return PC_LS_WALL_STEP;
+		W.cool = 1;      /* a cell edge or the capillary is within a step or two: one literal step, then try again */
 	}
 	if (W.cool > 0) W.cool--;
 
