@@ -78,21 +78,27 @@ def test_gpu_bit_identical_to_host_compile_with_leaks(pa, oracle, optic, leaks):
     E = [10.0, 20.0, 40.0]
     cs = [constants(leaks, e) for e in E]
     src = (0.05, 0.1, 0.1, 0.01, 0.01, 0., 0., 0.5)     # 10 mrad divergence: reflections and wall crossings mix
-    prob = problem(pa, optic, E, [a for a, _ in cs], [s for _, s in cs], source=src)
     ph = oracle.sample_photons(optic, oracle.make_source(*src), 31337, np.arange(500))
-    with pa.TraceContext(prob) as ctx:
-        g = ctx.launch_photons(ph[:, 0:3], ph[:, 3:6], ph[:, 6:9], leak_calc=True)
-        gext, gint = ctx.leaks()
-    e = pyemul.launch_leak(prob, ph[:, 0:3], ph[:, 3:6], ph[:, 6:9])
-    eext, eint = pyemul.sort_leak_records(e["records"])
-    for k in ("rc", "weights", "exit_coords", "exit_dir", "i_refl", "d_travel"):
-        assert np.array_equal(g[k], e[k], equal_nan=True), k
-    assert len(gext) + len(gint) > 100
-    # emulation records: slot, attempt, seq, kind, payload; kernel events: slot, attempt, payload
-    for got, exp in ((gext, eext), (gint, eint)):
-        assert got.shape[0] == exp.shape[0] and np.array_equal(got[:, 0], exp[:, 0])
-        assert np.array_equal(got[:, 2:12], exp[:, 4:14])                                  # coords, direction, elecv, n_refl
-        assert np.allclose(got[:, 12:], exp[:, 14:], rtol=1e-13, atol=0.)
+    for sig_rough in (0.0, 5.0):                         # smooth walls, and 5 Angstrom roughness (exp() in every weight)
+        prob = pa.Problem(optic.z, optic.cap, optic.ext, sig_rough, optic.n_cap, optic.density, E, [a for a, _ in cs],
+                          [s for _, s in cs], *src)
+        with pa.TraceContext(prob) as ctx:
+            g = ctx.launch_photons(ph[:, 0:3], ph[:, 3:6], ph[:, 6:9], leak_calc=True)
+            gext, gint = ctx.leaks()
+        e = pyemul.launch_leak(prob, ph[:, 0:3], ph[:, 3:6], ph[:, 6:9])
+        eext, eint = pyemul.sort_leak_records(e["records"])
+        for k in ("rc", "exit_coords", "exit_dir", "i_refl", "d_travel"):
+            assert np.array_equal(g[k], e[k], equal_nan=True), k
+        if sig_rough == 0.:
+            assert np.array_equal(g["weights"], e["weights"], equal_nan=True)
+        else:
+            assert np.allclose(g["weights"], e["weights"], rtol=1e-12, atol=1e-300, equal_nan=True)
+        assert len(gext) + len(gint) > 100
+        # emulation records: slot, attempt, seq, kind, payload; kernel events: slot, attempt, payload
+        for got, exp in ((gext, eext), (gint, eint)):
+            assert got.shape[0] == exp.shape[0] and np.array_equal(got[:, 0], exp[:, 0])
+            assert np.array_equal(got[:, 2:12], exp[:, 4:14])                              # coords, direction, elecv, n_refl
+            assert np.allclose(got[:, 12:], exp[:, 14:], rtol=1e-12, atol=0.)
 
 
 def test_explicit_photons_with_leaks_vs_oracle(pa, oracle, optic, leaks):
