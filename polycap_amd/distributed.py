@@ -67,8 +67,10 @@ def efficiencies_from_totals(counters, sums):
 
 
 def run_sharded(problem, seed, n_slots_total, rank=0, world_size=1, device_index=0, keep_images=False,
-                max_attempts=1 << 20, trace_fn=None, reduce_device=None):
-    """Trace this rank's share of [0, n_slots_total) and all-reduce the totals.
+                max_attempts=1 << 20, trace_fn=None, reduce_device=None, leak_calc=False):
+    """Trace this rank's share of [0, n_slots_total) and all-reduce the totals.  With leak_calc the leak events of the
+    rank's slots stay with the rank (local["ext"], local["int"], tagged with global slot numbers: concatenating the ranks'
+    arrays in rank order gives the single-device lists).
 
     trace_fn(problem, seed, slot0, n, keep_images, max_attempts) -> dict(counters, sumw_fixed, ...) replaces the
     HIP context in CPU-only tests of the sharding/reduction logic; the default is the GPU path."""
@@ -78,7 +80,7 @@ def run_sharded(problem, seed, n_slots_total, rank=0, world_size=1, device_index
         if trace_fn is None:
             from .hip import TraceContext
             with TraceContext(problem, device_index) as ctx:
-                local = ctx.transmission(seed, slot0, n, max_attempts=max_attempts, keep_images=keep_images)
+                local = ctx.transmission(seed, slot0, n, max_attempts=max_attempts, keep_images=keep_images, leak_calc=leak_calc)
         else:
             local = trace_fn(problem, seed, slot0, n, keep_images, max_attempts)
         vec = pack_totals(local["counters"], local["sumw_fixed"])

@@ -161,6 +161,11 @@ def test_driver_with_leaks_vs_oracle(pa, oracle, optic, leaks):
         both = np.concatenate([p[kind] for p in parts])
         assert np.array_equal(both, g[kind]) and np.array_equal(small[kind], g[kind])
     assert np.array_equal(g["counters"][:4], parts[0]["counters"][:4] + parts[1]["counters"][:4])
+    # the same through the multi-GPU entry point: two "ranks" on this device, events concatenated in rank order
+    from polycap_amd import distributed as pcd
+    ranks = [pcd.run_sharded(prob, 20000, n, rank=r, world_size=2, leak_calc=True) for r in (0, 1)]
+    for kind in ("ext", "int"):
+        assert np.array_equal(np.concatenate([r["local"][kind] for r in ranks]), g[kind])
 
 
 @pytest.mark.parametrize("binding", ["ctypes", "cython"])
