@@ -444,7 +444,7 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 			const long long n1 = (z_id != W.seg_step) ? 0 : W.nst;
 			const double b1 = (z_id != W.seg_step) ? W.dist : W.base;
 			const double qd = b1 + (double)(n1 + 1)*stp;
-			const double qx = Px + qd*dx, qy = Py + qd*dy, qz = Pz + qd*dz;
+			const double qz = Pz + qd*dz;                                          /* z of the landing point of the crossing step */
 			if (!(T.z[z_id+1] <= qz && qz < T.z[z_id+2])) break;
 			const double tB = (T.z[z_id+1] - W.pz)/dz * (1. + 1.e-9);            /* path length to the node */
 			if (pc_wall_piece_safe(Pm, Kx, Ky, inside_stack, W.px, W.py, W.pz - T.z[z_id], dx, dy, dz, tB, T.ext[z_id], es, T.cap[z_id], cs) <= 0) break;
