@@ -534,8 +534,8 @@ struct pc_hip_ctx {
 	float *d_ftables = nullptr;            /* mb1, md1, mb2, md2: 4 x npts */
 	/* options */
 	int literal = 0;
-	int event_threshold = 16;      /* tuned on MI355X, xos1 10 keV: scripts/ab_bench.sh */
-	int new_threshold = 4;
+	int event_threshold = 20;      /* tuned on MI355X, xos1 10 keV (scripts/sweep_opts.sh: flat within 1.5 % over 8..32 x 2..16 x 8..32) */
+	int new_threshold = 2;
 	int march_burst = 16;
 	int blocks_per_cu = 2;
 	int block_size = 512;
