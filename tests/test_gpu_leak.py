@@ -231,3 +231,27 @@ def test_public_api_with_leaks(pa, leaks, known, binding, monkeypatch):
             ratio = np.array([l.weight for l in ext]).sum(axis=0) / tot
             assert np.allclose(ratio, ratio[0], rtol=1e-12) and ratio[0] >= n
             assert H._units(path)["/ExternalLeaks/N_Reflections"] == "a.u."
+
+
+def test_long_profile_with_leaks(pa, oracle, leaks, known):
+    """1600-point profile: the leak kernel built for the wide LDS pitch (all seven tables, 144 KB) against the host compile"""
+    from tests.emul import pyemul
+    t = known["test_optic"]
+    long_optic = oracle.Optic.from_shape(t["type"], t["length"], t["rad_ext_upstream"], t["rad_ext_downstream"],
+                                         t["rad_int_upstream"], t["rad_int_downstream"], t["focal_dist_upstream"],
+                                         t["focal_dist_downstream"], t["sig_rough"], t["n_cap"], known["glass"]["density"], nmax=1599)
+    amu, scatf = constants(leaks, 40)
+    src = (0.05, 0.1, 0.1, 0.01, 0.01, 0., 0., 0.5)
+    prob = problem(pa, long_optic, [40.0], [amu], [scatf], source=src)
+    ph = oracle.sample_photons(long_optic, oracle.make_source(*src), 5, np.arange(300))
+    with pa.TraceContext(prob) as ctx:
+        g = ctx.launch_photons(ph[:, 0:3], ph[:, 3:6], ph[:, 6:9], leak_calc=True)
+        gext, gint = ctx.leaks()
+    e = pyemul.launch_leak(prob, ph[:, 0:3], ph[:, 3:6], ph[:, 6:9], max_depth=2048)
+    eext, eint = pyemul.sort_leak_records(e["records"])
+    for k in ("rc", "weights", "exit_coords", "exit_dir", "i_refl", "d_travel"):
+        assert np.array_equal(g[k], e[k], equal_nan=True), k
+    assert len(gext) > 50
+    for got, exp in ((gext, eext), (gint, eint)):
+        assert got.shape[0] == exp.shape[0] and np.array_equal(got[:, 2:12], exp[:, 4:14])
+        assert np.allclose(got[:, 12:], exp[:, 14:], rtol=1e-12, atol=0.)

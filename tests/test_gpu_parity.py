@@ -377,3 +377,28 @@ def test_command_line_program(pa, tmp_path):
         assert shapes["/PC_Exit/Coordinates"] == (3, 2000) and "/Input/PC_Shape" in shapes
         eff = H._read(out, "/Transmission_Efficiencies", str(tmp_path))
         assert np.all((eff >= 0) & (eff <= 1)) and eff.max() > 0
+
+
+def test_long_profile_uses_the_wide_lds_tables(pa, oracle):
+    """Profiles with more than 1024 points (up to 2048) run on the kernels built for the wide LDS pitch: identical to
+    the host compile of the device code, for one energy (register weights) and for three (weights in memory), and
+    in agreement with the oracle."""
+    from tests.emul import pyemul
+    from tests.common import TEST_SHAPE, GLASS, synthetic_constants
+    from polycap_amd import Problem
+    optic = oracle.Optic.from_shape(*TEST_SHAPE, 0.0, 200000, GLASS["density"], nmax=1599)
+    source = (2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.5)
+    ph = oracle.sample_photons(optic, oracle.make_source(*source), 11, np.arange(20000))
+    for energies in ((10.0,), (8.0, 10.0, 12.5)):
+        E = np.array(energies)
+        amu, scatf = (np.array([PIN_AMU]), np.array([PIN_SCATF])) if len(E) == 1 else synthetic_constants(E)
+        prob = Problem(optic.z, optic.cap, optic.ext, 0.0, 200000, GLASS["density"], E, amu, scatf, *source)
+        with pa.TraceContext(prob) as ctx:
+            g = ctx.launch_photons(ph[:, 0:3], ph[:, 3:6], ph[:, 6:9])
+            t = ctx.transmission(5, 0, 50000, keep_images=True)
+        e = pyemul.launch_batch(prob, ph[:, 0:3], ph[:, 3:6], ph[:, 6:9])
+        for k in g:
+            assert np.array_equal(g[k], e[k], equal_nan=True), (energies, k)
+        o = oracle.transmission(optic, oracle.make_source(*source), E, amu, scatf, 5, 0, 50000)
+        assert t["i_exit"] == 50000
+        assert np.all(np.abs(t["efficiencies"] - o["efficiencies"]) <= 4. / np.sqrt(o["i_start"]) * o["efficiencies"] + 1e-12)
