@@ -37,6 +37,9 @@
 #define PC_KE 5                /* energies per lane whose weights are in flight together in a cooperative sweep */
 #define PC_CHUNK 128           /* slots a wave takes from the global counter at a time */
 #define PC_FIX_SCALE 4611686018427387904.0 /* 2^62 */
+#ifndef PC_MIN_WAVES_NE0
+#define PC_MIN_WAVES_NE0 2     /* the any-n_energies kernel: 256 VGPRs (it spills 470 B per lane at 128), 8 waves per CU */
+#endif
 #ifndef PC_MIN_WAVES
 #define PC_MIN_WAVES 4         /* __launch_bounds__ waves per SIMD the register allocator must leave room for */
 #endif
@@ -76,6 +79,7 @@ struct pc_kargs {
 	double *img;                  /* [n_slots][17 + n_energies] records, or NULL */
 	int new_threshold;
 	int lds_acc;                  /* NE == 0: accumulate weight sums in LDS (2*n_energies u64 of dynamic LDS) */
+	int lds_ec;                   /* NE == 0: per-energy constants staged in LDS behind the sums (6*n_energies doubles) */
 	double *wscratch;             /* NE==0: n_energies * total_threads */
 	long long total_threads;
 	/* explicit-photon mode */
@@ -112,7 +116,7 @@ __device__ __forceinline__ void pc_atomic_add128(unsigned long long *lohi, unsig
 enum { PC_MODE_SRC_CIRCULAR = 0, PC_MODE_SRC_GENERIC = 1, PC_MODE_EXPLICIT = 2 };
 
 template <int NE, int MODE, int PITCH>
-__global__ void __launch_bounds__(PC_BLOCK, PC_MIN_WAVES)
+__global__ void __launch_bounds__(PC_BLOCK, NE == 0 ? PC_MIN_WAVES_NE0 : PC_MIN_WAVES)
 pc_trace_kernel(pc_kargs a)
 {
 	constexpr bool EXPLICIT = (MODE == PC_MODE_EXPLICIT);
@@ -134,6 +138,14 @@ pc_trace_kernel(pc_kargs a)
 	}
 	if (NE != 1 && a.lds_acc)
 		for (int k = threadIdx.x; k < 2*a.pm.n_energies; k += blockDim.x) l_acc[k] = 0ull;
+	/* NE == 0: the per-energy constants of the cooperative sweeps, staged behind the sums when they fit (a.lds_ec):
+	 * every reflection of every photon reads all 6*n_energies of them */
+	const double *ecs = a.ec_soa;
+	if (NE == 0 && a.lds_ec) {
+		double *l_ec = (double *)(l_acc + 2*a.pm.n_energies);
+		for (int k = threadIdx.x; k < 6*a.pm.n_energies; k += blockDim.x) l_ec[k] = a.ec_soa[k];
+		ecs = l_ec;
+	}
 	__syncthreads();
 	pc_tables T;
 	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.hexd = l_hexd; T.idz = l_idz; T.ext = a.g_ext;
@@ -222,6 +234,65 @@ pc_trace_kernel(pc_kargs a)
 				}
 				unsigned long long mP = __ballot(pend == 1);
 				const long long wave_gtid0 = gtid - lane;
+				if (ne <= 32) {
+					/* up to 32 energies: the wave is split into 64/G groups of G = 16 or 32 lanes and sweeps that many
+					 * pending photons per pass (lane = photon group x energy); four passes are in flight together so that
+					 * the latency of their weight loads (the weights live in HBM/L2) is paid once per batch, not per pass */
+					const int G = (ne <= 16) ? 16 : 32, PP = PC_WAVE / G;
+					const int sub = lane / G, e = lane - sub*G;
+					const unsigned long long gm = (G == 32) ? 0xffffffffull : 0xffffull;
+					pc_energy_const ec;
+					ec.n_re = ec.n_im = ec.ninv2_re = ec.ninv2_im = ec.rough_c = ec.valid = 0.;
+					if (e < ne) {
+						ec.n_re = ecs[e]; ec.n_im = ecs[ne + e];
+						ec.ninv2_re = ecs[2*ne + e]; ec.ninv2_im = ecs[3*ne + e];
+						ec.rough_c = ecs[4*ne + e]; ec.valid = ecs[5*ne + e];
+					}
+					while (mP) {
+						int srcv[4], myslot = -1;
+#pragma unroll
+						for (int j = 0; j < 4; j++) {
+							srcv[j] = -1;
+							for (int k = 0; k < PP && mP; k++) {
+								const int p = __ffsll((long long)mP) - 1;
+								mP &= mP - 1ull;
+								if (sub == k) srcv[j] = p;
+								if (lane == p) myslot = 4*j + k;
+							}
+						}
+						double wv[4];
+#pragma unroll
+						for (int j = 0; j < 4; j++) {
+							const int from = (srcv[j] < 0) ? 0 : srcv[j];
+							const int wset_p = __shfl(ph.wset, from, PC_WAVE);
+							wv[j] = (srcv[j] >= 0 && e < ne && wset_p) ? a.wscratch[(wave_gtid0 + srcv[j])*(long long)ne + e] : 1.0;
+						}
+						unsigned long long mBv[4], mKv[4];
+#pragma unroll
+						for (int j = 0; j < 4; j++) {
+							const int from = (srcv[j] < 0) ? 0 : srcv[j];
+							pc_refl_geom gp;
+							gp.alfa = __shfl(g.alfa, from, PC_WAVE); gp.st2 = __shfl(g.st2, from, PC_WAVE);
+							gp.es2 = __shfl(g.es2, from, PC_WAVE); gp.ep2 = __shfl(g.ep2, from, PC_WAVE); gp.sd2 = __shfl(g.sd2, from, PC_WAVE);
+							int bad = 0, keep = 0;
+							if (srcv[j] >= 0 && e < ne) {
+								int r = pc_reflect_energy(ec, gp, wv[j]);
+								a.wscratch[(wave_gtid0 + srcv[j])*(long long)ne + e] = wv[j];
+								bad = (r < 0);
+								keep = (r > 0);
+							}
+							mBv[j] = __ballot(bad);
+							mKv[j] = __ballot(keep);
+						}
+						if (myslot >= 0) {
+							const int j = myslot >> 2, k = myslot & 3;
+							const unsigned long long m = gm << (k*G);
+							const unsigned long long B = (j == 0) ? mBv[0] : ((j == 1) ? mBv[1] : ((j == 2) ? mBv[2] : mBv[3]));
+							const unsigned long long K = (j == 0) ? mKv[0] : ((j == 1) ? mKv[1] : ((j == 2) ? mKv[2] : mKv[3]));
+							res = (B & m) ? -1 : ((K & m) ? 1 : 0);
+						}
+					}
+				} else
 				while (mP) {
 					const int p = __ffsll((long long)mP) - 1;
 					mP &= mP - 1ull;
@@ -244,9 +315,9 @@ pc_trace_kernel(pc_kargs a)
 							const int e = e0 + k*PC_WAVE + lane;
 							if (e < ne) {
 								pc_energy_const ec;
-								ec.n_re = a.ec_soa[e]; ec.n_im = a.ec_soa[ne + e];
-								ec.ninv2_re = a.ec_soa[2*ne + e]; ec.ninv2_im = a.ec_soa[3*ne + e];
-								ec.rough_c = a.ec_soa[4*ne + e]; ec.valid = a.ec_soa[5*ne + e];
+								ec.n_re = ecs[e]; ec.n_im = ecs[ne + e];
+								ec.ninv2_re = ecs[2*ne + e]; ec.ninv2_im = ecs[3*ne + e];
+								ec.rough_c = ecs[4*ne + e]; ec.valid = ecs[5*ne + e];
 								int r = pc_reflect_energy(ec, gp, wv[k]);
 								wp[e] = wv[k];
 								bad |= (r < 0);
@@ -539,6 +610,7 @@ struct pc_hip_ctx {
 	int march_burst = 16;
 	int blocks_per_cu = 2;
 	int block_size = 512;
+	int lds_ec = 1;                /* many-energy runs: per-energy constants in LDS, one 1024-thread workgroup per CU */
 	/* last run */
 	pc_totals *d_totals = nullptr;         /* pc_totals + 2*nE u64 */
 	size_t totals_bytes = 0;
@@ -597,11 +669,13 @@ template <int NE, int MODE>
 static int pc_launch_one(pc_hip_ctx *ctx, const pc_kargs &a, int grid)
 {
 	/* table pitch: 1024 entries (48 KB of LDS) covers the reference's generated profiles (nmax = 999) and its example decks */
-	const size_t dyn = (NE != 1 && a.lds_acc) ? 2*(size_t)ctx->host.pm.n_energies*sizeof(unsigned long long) : 0;
+	const size_t dyn = ((NE != 1 && a.lds_acc) ? 2*(size_t)ctx->host.pm.n_energies*sizeof(unsigned long long) : 0)
+	                 + ((NE == 0 && a.lds_ec) ? 6*(size_t)ctx->host.pm.n_energies*sizeof(double) : 0);
+	const int block = (int)(a.total_threads / grid);
 	if (ctx->host.pm.nmax + 1 <= 1024)
-		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, 1024>), dim3(grid), dim3(ctx->block_size), dyn, ctx->stream, a);
+		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, 1024>), dim3(grid), dim3(block), dyn, ctx->stream, a);
 	else if (NE <= 1)   /* long profiles: only the NE = 1 and the any-n_energies kernels are built for the 2048 pitch */
-		hipLaunchKernelGGL((pc_trace_kernel<(NE <= 1 ? NE : 0), MODE, PC_MAX_PITCH>), dim3(grid), dim3(ctx->block_size), dyn, ctx->stream, a);
+		hipLaunchKernelGGL((pc_trace_kernel<(NE <= 1 ? NE : 0), MODE, PC_MAX_PITCH>), dim3(grid), dim3(block), dyn, ctx->stream, a);
 	else
 		return pc_fail(PC_HIP_ERR_INVALID, "internal: register-weight kernels are built for profiles of up to 1024 points");
 	PC_HIP_CHECK(hipGetLastError());
@@ -612,15 +686,18 @@ template <int MODE>
 static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 {
 	const int ne = ctx->host.pm.n_energies;
-	long long max_blocks = (long long)ctx->n_cu * ctx->blocks_per_cu;
+	/* weights in registers for up to 8 energies (kernels NE = 1, 4, 8), in the per-lane scratch beyond */
+	const int kne = (ne == 1) ? 1 : ((ne <= 4 && ctx->host.pm.nmax + 1 <= 1024) ? 4 : ((ne <= 8 && ctx->host.pm.nmax + 1 <= 1024) ? 8 : 0));
+	a.lds_acc = (ne != 1 && 2*(size_t)ne*sizeof(unsigned long long) <= 16384) ? 1 : 0;
+	/* many energies on a profile of up to 1024 points: one workgroup of 1024 threads per CU (the same 16 waves as two of
+	 * 512) leaves room in LDS for the per-energy constants next to the tables and the sums */
+	a.lds_ec = (kne == 0 && a.lds_acc && ctx->lds_ec && ctx->host.pm.nmax + 1 <= 1024 && 64*(size_t)ne <= 28672) ? 1 : 0;
+	long long max_blocks = (long long)ctx->n_cu * ((kne == 0) ? 1 : ctx->blocks_per_cu);
 	const int block = ctx->block_size;
 	long long want_blocks = (n_items + block - 1) / block;
 	int grid = (int)(want_blocks < max_blocks ? want_blocks : max_blocks);
 	if (grid < 1) grid = 1;
 	a.total_threads = (long long)grid * block;
-	/* weights in registers for up to 8 energies (kernels NE = 1, 4, 8), in the per-lane scratch beyond */
-	const int kne = (ne == 1) ? 1 : ((ne <= 4 && ctx->host.pm.nmax + 1 <= 1024) ? 4 : ((ne <= 8 && ctx->host.pm.nmax + 1 <= 1024) ? 8 : 0));
-	a.lds_acc = (ne != 1 && 2*(size_t)ne*sizeof(unsigned long long) <= 16384) ? 1 : 0;
 	if (kne == 0) {
 		size_t need = (size_t)ne * (size_t)a.total_threads;
 		if (need > ctx->wscratch_elems) {
@@ -749,6 +826,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "march_burst") { if (value < 1) return pc_fail(PC_HIP_ERR_INVALID, "march_burst must be >= 1"); ctx->march_burst = (int)value; }
 	else if (n == "block_size") { if (value < 64 || value > PC_BLOCK || (value % 64) != 0) return pc_fail(PC_HIP_ERR_INVALID, "block_size must be a multiple of 64 up to the compiled maximum"); ctx->block_size = (int)value; }
 	else if (n == "blocks_per_cu") { if (value < 1 || value > 8) return pc_fail(PC_HIP_ERR_INVALID, "blocks_per_cu must be in [1,8]"); ctx->blocks_per_cu = (int)value; }
+	else if (n == "lds_ec") ctx->lds_ec = value ? 1 : 0;
 	else if (n == "leak_max_depth") { if (value < 2 || value > (1 << 20)) return pc_fail(PC_HIP_ERR_INVALID, "leak_max_depth must be in [2, 2^20]"); ctx->leak_max_depth = (int)value; }
 	else if (n == "leak_stack_mb") { if (value < 1) return pc_fail(PC_HIP_ERR_INVALID, "leak_stack_mb must be >= 1"); ctx->leak_stack_bytes = (size_t)value << 20; }
 	else if (n == "leak_capacity") { if (value < 0) return pc_fail(PC_HIP_ERR_INVALID, "leak_capacity must be >= 0"); ctx->leak_capacity = (long long)value; }
