@@ -28,7 +28,7 @@ import numpy as np
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this same command, condensed by scripts/summarize_profile.py
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "v7_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "v8_pmc_summary.json")
 
 
 def measured_traffic(n_local, keep_images):
