@@ -15,7 +15,6 @@
 #define PC_PROBLEM_H
 
 #include <cmath>
-#include <complex>
 #include <string>
 #include <vector>
 
@@ -128,11 +127,14 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 		pc_energy_const &c = t.ec[k];
 		double alfa = (PC_HC/e)*(PC_HC/e)*((PC_N_AVOG*PC_R0*p->density)/(2*PC_PI)) * scatf;
 		double beta = (PC_HC)/(4.*PC_PI) * (amu/e);
-		std::complex<double> nn(1.0 - alfa, beta);
-		std::complex<double> ninv = 1.0/nn;
-		std::complex<double> ninv2 = ninv*ninv;
-		c.n_re = nn.real(); c.n_im = nn.imag();
-		c.ninv2_re = ninv2.real(); c.ninv2_im = ninv2.imag();
+		/* n = (1 - alfa) + i beta, 1/n and (1/n)^2 in plain real arithmetic: std::complex division and multiplication are
+		 * implemented differently by different compilers/runtimes (scaled library calls or inline formulas), and these
+		 * constants must come out the same wherever this header is compiled */
+		const double nre = 1.0 - alfa, nim = beta;
+		const double nn2 = nre*nre + nim*nim;
+		const double ire = nre/nn2, iim = -nim/nn2;
+		c.n_re = nre; c.n_im = nim;
+		c.ninv2_re = ire*ire - iim*iim; c.ninv2_im = 2.*(ire*iim);
 		c.rough_c = (1.01358e0*e)*p->sig_rough;
 		/* argument checks of polycap_refl_polar, src/polycap-capil.c:463-478 */
 		c.valid = (e >= 1. && e <= 100. && p->density > 0. && scatf >= 0. && amu >= 0.) ? 1. : 0.;

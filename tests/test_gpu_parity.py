@@ -402,3 +402,28 @@ def test_long_profile_uses_the_wide_lds_tables(pa, oracle):
         o = oracle.transmission(optic, oracle.make_source(*source), E, amu, scatf, 5, 0, 50000)
         assert t["i_exit"] == 50000
         assert np.all(np.abs(t["efficiencies"] - o["efficiencies"]) <= 4. / np.sqrt(o["i_start"]) * o["efficiencies"] + 1e-12)
+
+
+@pytest.mark.parametrize("n_energies", [12, 24, 40, 291])
+def test_many_energies_match_the_host_compile(pa, oracle, n_energies):
+    """The any-n_energies kernel (weights in memory, cooperative sweeps: 4 photons per pass up to 16 energies, 2 up to 32,
+    one beyond) against the host compile of the device code, bit for bit, and the driver against the oracle."""
+    from tests.emul import pyemul
+    energies = np.linspace(3.0, 30.0, n_energies)
+    optic, src, prob, (E, A, S) = make_pair(oracle, "xos1", energies=energies)
+    ph = _photons(oracle, optic, src, 6000, seed=3)
+    with pa.TraceContext(prob) as ctx:
+        g = ctx.launch_photons(ph[:, 0:3], ph[:, 3:6], ph[:, 6:9])
+        t = ctx.transmission(9, 0, 20000, keep_images=True)
+    e = pyemul.launch_batch(prob, ph[:, 0:3], ph[:, 3:6], ph[:, 6:9])
+    for k in g:
+        assert np.array_equal(g[k], e[k], equal_nan=True), k
+    o = oracle.transmission(optic, src, E, A, S, 9, 0, 20000)
+    assert t["i_exit"] == 20000
+    assert np.all(np.abs(t["efficiencies"] - o["efficiencies"]) <= 4. / np.sqrt(o["i_start"]) * o["efficiencies"] + 1e-12)
+    w = t["exit_weights"]
+    assert w.shape == (20000, n_energies) and np.all((w >= 0) & (w <= 1)) and np.all(w.max(axis=1) >= 1e-4)
+    # checksum of checksums: the per-slot weights add up to the exact fixed-point totals, energy by energy
+    for k in (0, n_energies // 2, n_energies - 1):
+        tot = int(t["sumw_fixed"][k, 0]) + (int(t["sumw_fixed"][k, 1]) << 64)
+        assert sum(int(x) for x in np.floor(w[:, k] * 4611686018427387904.0).astype(np.uint64)) == tot
