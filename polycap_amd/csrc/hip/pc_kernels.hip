@@ -174,8 +174,10 @@ pc_trace_kernel(pc_kargs a)
 
 	/* per-lane totals */
 	/* 32 bits per lane are plenty (a lane handles n_slots / total_threads slots); the wave sums are 64-bit */
-	unsigned int n_exit = 0, n_not_entered = 0, n_not_trans = 0, s_irefl = 0, n_failed = 0, n_launch = 0;
-	unsigned long long acc_lo[1] = {0}, acc_hi[1] = {0};   /* NE == 1: per-lane exact sum; NE > 1 and NE == 0 sum in LDS */
+	/* wave-uniform totals (scalar registers): the lanes' contributions are gathered with ballots / wave sums at the end
+	 * of every NEW phase, so no per-lane counter stays live across the march and event loops */
+	unsigned long long u_exit = 0, u_not_entered = 0, u_not_trans = 0, u_irefl = 0, u_failed = 0, u_launch = 0;
+	unsigned long long u_acc_lo = 0, u_acc_hi = 0;   /* NE == 1: exact 128-bit weight sum; NE > 1 and NE == 0 sum in LDS */
 
 	/* wave-uniform scheduler statistics (diagnostics: lane utilisation per phase type) */
 	unsigned long long st_march = 0, st_march_l = 0, st_event = 0, st_event_l = 0, st_new = 0, st_new_l = 0;
@@ -337,6 +339,9 @@ pc_trace_kernel(pc_kargs a)
 			st_new += 1; st_new_l += (unsigned)nN;
 			/* ---------------- NEW: finalise finished photons, hand out slots, sample + entrance tests */
 			int coop = 0;                 /* NE == 0: what the cooperative weight sweep has to do for this lane's photon */
+			int f_exit = 0, f_not_entered = 0, f_not_trans = 0, f_failed = 0, f_launch = 0;   /* this lane's contributions */
+			unsigned int f_irefl = 0;
+			unsigned long long f_w = 0;
 			const long long done_slot = slot;
 			if (state == LS_DONE) {
 				const int rc = ph.rc;
@@ -358,18 +363,15 @@ pc_trace_kernel(pc_kargs a)
 				} else {
 					/* src/polycap-source.c:758-777 */
 					int ok = 0;
-					if (rc == 0) n_not_trans++;
-					else if (rc == 2) n_not_entered++;
+					if (rc == 0) f_not_trans = 1;
+					else if (rc == 2) f_not_entered = 1;
 					else if (rc == 1) ok = pc_in_exit_window(Pm, ph);
 					if (ok) {
-						n_exit++;
-						s_irefl += (unsigned int)ph.irefl;
+						f_exit = 1;
+						f_irefl = (unsigned int)ph.irefl;
 						if (NE == 1) {
 							double w = ph.w[0];
-							unsigned long long f = (unsigned long long)(w * PC_FIX_SCALE);
-							unsigned long long old = acc_lo[0];
-							acc_lo[0] = old + f;
-							acc_hi[0] += (old + f < old) ? 1ull : 0ull;
+							f_w = (unsigned long long)(w * PC_FIX_SCALE);
 							if (a.keep_images) a.img[slot*rec + PC_F_WEIGHTS] = w;
 						} else if (NE > 1) {
 							/* a few energies: exact sums in LDS (2 x u64 per energy), flushed once per workgroup */
@@ -405,7 +407,7 @@ pc_trace_kernel(pc_kargs a)
 					} else {
 						attempt++;
 						if (attempt >= a.max_attempts) {
-							n_failed++;
+							f_failed = 1;
 							if (a.keep_images) {
 								if (NE > 0) for (int e = 0; e < ner; e++) a.img[slot*rec + PC_F_WEIGHTS + e] = 0.;
 								else coop = 2;   /* zero weights */
@@ -477,7 +479,7 @@ pc_trace_kernel(pc_kargs a)
 			}
 			/* start an attempt */
 			if (state == LS_START) {
-				n_launch++;
+				f_launch = 1;
 				if (EXPLICIT) {
 					const long long j = slot;
 					state = pc_launch_init(T, Pm, ph, a.in_start[3*j], a.in_start[3*j+1], a.in_start[3*j+2],
@@ -512,6 +514,25 @@ pc_trace_kernel(pc_kargs a)
 					}
 				}
 			}
+			/* gather this phase's contributions into the wave-uniform totals */
+			u_not_trans += (unsigned long long)__popcll(__ballot(f_not_trans));
+			u_not_entered += (unsigned long long)__popcll(__ballot(f_not_entered));
+			u_failed += (unsigned long long)__popcll(__ballot(f_failed));
+			u_launch += (unsigned long long)__popcll(__ballot(f_launch));
+			const unsigned long long mX = __ballot(f_exit);
+			if (mX) {
+				u_exit += (unsigned long long)__popcll(mX);
+				u_irefl += pc_wave_sum_u64((unsigned long long)f_irefl);
+				if (NE == 1) {
+					/* exact 128-bit accumulation of the wave's 64-bit fixed-point weights through two 32-bit partial sums */
+					const unsigned long long s_low = pc_wave_sum_u64(f_w & 0xffffffffull), s_high = pc_wave_sum_u64(f_w >> 32);
+					const unsigned long long lo = s_low + (s_high << 32);
+					const unsigned long long hi = (s_high >> 32) + ((lo < s_low) ? 1ull : 0ull);
+					const unsigned long long old = u_acc_lo;
+					u_acc_lo = old + lo;
+					u_acc_hi += hi + ((u_acc_lo < old) ? 1ull : 0ull);
+				}
+			}
 		}
 	}
 
@@ -522,8 +543,7 @@ pc_trace_kernel(pc_kargs a)
 	}
 	if (!EXPLICIT) {
 		/* one set of atomics per wave */
-		unsigned long long v0 = pc_wave_sum_u64(n_exit), v1 = pc_wave_sum_u64(n_not_entered), v2 = pc_wave_sum_u64(n_not_trans);
-		unsigned long long v3 = pc_wave_sum_u64(s_irefl), v4 = pc_wave_sum_u64(n_failed), v5 = pc_wave_sum_u64(n_launch);
+		const unsigned long long v0 = u_exit, v1 = u_not_entered, v2 = u_not_trans, v3 = u_irefl, v4 = u_failed, v5 = u_launch;
 		if (lane == 0) {
 			atomicAdd(&a.totals->counters[0], v0);
 			atomicAdd(&a.totals->counters[1], v1);
@@ -535,20 +555,8 @@ pc_trace_kernel(pc_kargs a)
 			atomicAdd(&a.totals->phase[2], st_event); atomicAdd(&a.totals->phase[3], st_event_l);
 			atomicAdd(&a.totals->phase[4], st_new); atomicAdd(&a.totals->phase[5], st_new_l);
 		}
-		if (NE == 1) {
-#pragma unroll
-			for (int e = 0; e < 1; e++) {
-				/* exact wave sum of 128-bit values through three 64-bit partial sums */
-				unsigned long long s_hi = pc_wave_sum_u64(acc_hi[e]);
-				unsigned long long s_mid = pc_wave_sum_u64(acc_lo[e] >> 32);
-				unsigned long long s_low = pc_wave_sum_u64(acc_lo[e] & 0xffffffffull);
-				if (lane == 0) {
-					unsigned long long lo = s_low + (s_mid << 32);
-					unsigned long long hi = s_hi + (s_mid >> 32) + ((lo < s_low) ? 1ull : 0ull);
-					pc_atomic_add128(a.sumw + 2*e, lo, hi);
-				}
-			}
-		}
+		if (NE == 1 && lane == 0)
+			pc_atomic_add128(a.sumw, u_acc_lo, u_acc_hi);
 	}
 }
 
