@@ -100,6 +100,7 @@ struct pc_photon {
 	int wset;               /* NE == 0: the in-memory weights have been written (before that every weight is 1) */
 	int lv;                 /* widest block-certificate stride still allowed on this flight: 0 single segments, 1 L1, 2 L2 */
 	int rc;                 /* final polycap_photon_launch return code once DONE */
+	int qr;                 /* hexagonal (q, r) indices of the capillary, (q + 32768) << 16 | (r + 32768): kx, ky, kn follow from them */
 };
 
 /* ------------------------------------------------------------------ small helpers */
@@ -284,9 +285,18 @@ PC_HD int pc_last_node_le(const pc_tables &T, int upto, double zval)
 	return idx;
 }
 
+/* capillary axis scale factors from the hexagonal indices: src/polycap-photon.c:624-627 */
+template <int NE>
+PC_HD void pc_axis_setup(pc_photon<NE> &ph, double q_i, double r_i)
+{
+	ph.ky = r_i * (3./2);
+	ph.kx = (2.*q_i + r_i) * PC_COSPI_6;
+	ph.kn = sqrt(ph.kx*ph.kx + ph.ky*ph.ky);
+}
+
 /* begin a polycap_capil_trace call at segment ph.i: src/polycap-capil.c:1236-1243 */
 template <int NE>
-PC_HD void pc_trace_begin(pc_photon<NE> &ph)
+PC_HD void pc_ray_setup(pc_photon<NE> &ph)
 {
 	double idz = 1.0 / ph.dz;
 	ph.idzd = idz;
@@ -294,6 +304,12 @@ PC_HD void pc_trace_begin(pc_photon<NE> &ph)
 	ph.sy = ph.dy * idz;
 	ph.ox = ph.Px - ph.sx * ph.Pz;
 	ph.oy = ph.Py - ph.sy * ph.Pz;
+}
+
+template <int NE>
+PC_HD void pc_trace_begin(pc_photon<NE> &ph)
+{
+	pc_ray_setup(ph);
 	ph.first = 1;
 	/* long first flight: start with the widest stride; after a reflection flights are short */
 	ph.lv = ph.bnd ? 0 : ((ph.irefl == 0) ? 2 : 1);
@@ -350,9 +366,8 @@ PC_HD int pc_launch_init(const pc_tables &T, const pc_params &Pm, pc_photon<NE> 
 		if (pc_outside_hex(cur_ext, x, y)) { ph.rc = -2; return PC_ST_DONE; }
 	}
 	/* :624-627 */
-	ph.ky = r_i * (3./2);
-	ph.kx = (2.*q_i + r_i) * PC_COSPI_6;
-	ph.kn = sqrt(ph.kx*ph.kx + ph.ky*ph.ky);
+	pc_axis_setup(ph, q_i, r_i);
+	ph.qr = (((int)q_i + 32768) << 16) | ((int)r_i + 32768);
 	ph.i = (z > 0) ? pc_last_node_le(T, nmax + 1, z) : 0;
 	/* :629-645 */
 	double cur_rad, cur_cx, cur_cy;

@@ -80,6 +80,8 @@ struct pc_kargs {
 	int new_threshold;
 	int lds_acc;                  /* NE == 0: accumulate weight sums in LDS (2*n_energies u64 of dynamic LDS) */
 	int lds_ec;                   /* NE == 0: per-energy constants staged in LDS behind the sums (6*n_energies doubles) */
+	int pool_event_min;           /* pool kernel: photons waiting for an EVENT phase that make it run before anything else */
+	int pool_refill;              /* pool kernel: lanes that must be free before a march burst tops itself up from the pool */
 	double *wscratch;             /* NE==0: n_energies * total_threads */
 	long long total_threads;
 	/* explicit-photon mode */
@@ -560,6 +562,8 @@ pc_trace_kernel(pc_kargs a)
 	}
 }
 
+#include "pc_pool_kernel.h"
+
 /* source sampling only (parity of polycap_source_get_photon) */
 __global__ void pc_sample_kernel(pc_params pm, unsigned long long seed, long long n,
                                  const long long *slots, const unsigned int *attempts, double *out)
@@ -618,6 +622,11 @@ struct pc_hip_ctx {
 	int march_burst = 16;
 	int blocks_per_cu = 2;
 	int block_size = 512;
+	int pool = 0;                  /* single-energy source runs: per-wave photon pool in LDS (pc_pool_kernel.h) */
+	int pool_refill = 20;
+	int pool_march_min = 16;
+	int pool_event_min = 48;
+	int pool_new_min = 48;
 	int lds_ec = 1;                /* many-energy runs: per-energy constants in LDS, one 1024-thread workgroup per CU */
 	/* last run */
 	pc_totals *d_totals = nullptr;         /* pc_totals + 2*nE u64 */
@@ -669,6 +678,7 @@ static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
 	a.event_threshold = ctx->event_threshold;
 	a.new_threshold = ctx->new_threshold;
 	a.march_burst = ctx->march_burst;
+	a.pool_refill = ctx->pool_refill;
 	a.totals = ctx->d_totals;
 	a.sumw = (unsigned long long *)(ctx->d_totals + 1);
 }
@@ -690,6 +700,22 @@ static int pc_launch_one(pc_hip_ctx *ctx, const pc_kargs &a, int grid)
 	return PC_HIP_OK;
 }
 
+/* the pool kernel serves single-energy source runs on profiles of up to 1024 points (what its packed records hold) */
+template <int MODE>
+static bool pc_pool_applies(const pc_hip_ctx *ctx, const pc_kargs &a)
+{
+	const pc_params &pm = ctx->host.pm;
+	return MODE != PC_MODE_EXPLICIT && ctx->pool && pm.n_energies == 1 && !ctx->literal && pm.nmax + 1 <= PQ_PITCH
+	    && a.max_attempts <= (1u << 24) && pm.n_shells < 16000. && a.n_slots < (1ll << 39);
+}
+
+template <int MODE>
+static void pc_launch_pool(pc_hip_ctx *ctx, const pc_kargs &a, int grid)
+{
+	if constexpr (MODE != PC_MODE_EXPLICIT)
+		hipLaunchKernelGGL((pc_trace_pool_kernel<MODE>), dim3(grid), dim3(PQ_BLOCK), 0, ctx->stream, a);
+}
+
 template <int MODE>
 static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 {
@@ -700,6 +726,22 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 	/* many energies on a profile of up to 1024 points: one workgroup of 1024 threads per CU (the same 16 waves as two of
 	 * 512) leaves room in LDS for the per-energy constants next to the tables and the sums */
 	a.lds_ec = (kne == 0 && a.lds_acc && ctx->lds_ec && ctx->host.pm.nmax + 1 <= 1024 && 64*(size_t)ne <= 28672) ? 1 : 0;
+	if (pc_pool_applies<MODE>(ctx, a)) {
+		/* one 1024-thread workgroup per CU; a wave holds 64 + PQ_P photons */
+		const long long per_block = (long long)PQ_WAVES*(PC_WAVE + PQ_P);
+		long long want = (n_items + per_block - 1) / per_block;
+		int grid = (int)(want < ctx->n_cu ? want : ctx->n_cu);
+		if (grid < 1) grid = 1;
+		a.total_threads = (long long)grid * PQ_BLOCK;
+		a.event_threshold = ctx->pool_march_min;
+		a.pool_event_min = ctx->pool_event_min;
+		a.new_threshold = ctx->pool_new_min;
+		PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+		pc_launch_pool<MODE>(ctx, a, grid);
+		PC_HIP_CHECK(hipGetLastError());
+		PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+		return PC_HIP_OK;
+	}
 	long long max_blocks = (long long)ctx->n_cu * ((kne == 0) ? 1 : ctx->blocks_per_cu);
 	const int block = ctx->block_size;
 	long long want_blocks = (n_items + block - 1) / block;
@@ -835,6 +877,11 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "block_size") { if (value < 64 || value > PC_BLOCK || (value % 64) != 0) return pc_fail(PC_HIP_ERR_INVALID, "block_size must be a multiple of 64 up to the compiled maximum"); ctx->block_size = (int)value; }
 	else if (n == "blocks_per_cu") { if (value < 1 || value > 8) return pc_fail(PC_HIP_ERR_INVALID, "blocks_per_cu must be in [1,8]"); ctx->blocks_per_cu = (int)value; }
 	else if (n == "lds_ec") ctx->lds_ec = value ? 1 : 0;
+	else if (n == "pool") ctx->pool = value ? 1 : 0;
+	else if (n == "pool_refill") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "pool_refill must be in [1,64]"); ctx->pool_refill = (int)value; }
+	else if (n == "pool_event_min") { if (value < 1 || value > 128) return pc_fail(PC_HIP_ERR_INVALID, "pool_event_min must be in [1,128]"); ctx->pool_event_min = (int)value; }
+	else if (n == "pool_new_min") { if (value < 1 || value > 128) return pc_fail(PC_HIP_ERR_INVALID, "pool_new_min must be in [1,128]"); ctx->pool_new_min = (int)value; }
+	else if (n == "pool_march_min") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "pool_march_min must be in [1,64]"); ctx->pool_march_min = (int)value; }
 	else if (n == "leak_max_depth") { if (value < 2 || value > (1 << 20)) return pc_fail(PC_HIP_ERR_INVALID, "leak_max_depth must be in [2, 2^20]"); ctx->leak_max_depth = (int)value; }
 	else if (n == "leak_stack_mb") { if (value < 1) return pc_fail(PC_HIP_ERR_INVALID, "leak_stack_mb must be >= 1"); ctx->leak_stack_bytes = (size_t)value << 20; }
 	else if (n == "leak_capacity") { if (value < 0) return pc_fail(PC_HIP_ERR_INVALID, "leak_capacity must be >= 0"); ctx->leak_capacity = (long long)value; }

@@ -427,3 +427,32 @@ def test_many_energies_match_the_host_compile(pa, oracle, n_energies):
     for k in (0, n_energies // 2, n_energies - 1):
         tot = int(t["sumw_fixed"][k, 0]) + (int(t["sumw_fixed"][k, 1]) << 64)
         assert sum(int(x) for x in np.floor(w[:, k] * 4611686018427387904.0).astype(np.uint64)) == tot
+
+
+def test_photon_pool_kernel_is_bit_identical(pa, oracle):
+    """Option "pool": photons parked in LDS are exchanged between lanes (pc_pool_kernel.h).  A photon depends on
+    (seed, slot, attempt) only and the sums are exact, so totals and every image plane equal the lane kernel's."""
+    from tests.common import make_custom, MONO_CASE, SEVEN_CASE
+    probs = [make_pair(oracle, "xos1")[2], make_pair(oracle, "xos1", source=(2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.0))[2],
+             make_custom(oracle, **MONO_CASE)[2], make_custom(oracle, **SEVEN_CASE)[2]]
+    for k, prob in enumerate(probs):
+        for n, max_attempts in ((60000, 1 << 20), (37, 1 << 20), (3000, 2)):
+            with pa.TraceContext(prob) as ctx:
+                ctx.run(31 + k, 1000, n, max_attempts=max_attempts, keep_images=True)
+                ctx.wait()
+                a = ctx.totals(check=False)
+                a.update(ctx.images(0, n))
+                ctx.set_option("pool", 1)
+                ctx.run(31 + k, 1000, n, max_attempts=max_attempts, keep_images=True)
+                ctx.wait()
+                b = ctx.totals(check=False)
+                b.update(ctx.images(0, n))
+                swaps = ctx.phase_stats()
+            assert np.array_equal(a["counters"], b["counters"]) and np.array_equal(a["sumw_fixed"], b["sumw_fixed"]), (k, n)
+            assert np.array_equal(a["exit_weights"], b["exit_weights"]), (k, n)
+            done = a["exit_weights"][:, 0] > 0        # a slot that ran out of attempts has weight 0 and no defined exit planes
+            assert np.array_equal(a["images"][done], b["images"][done], equal_nan=True), (k, n)
+            assert np.array_equal(a["images"][~done, :8], b["images"][~done, :8], equal_nan=True), (k, n)
+            if max_attempts == 2:
+                assert a["failed_slots"] > 0 and not done.all()
+            assert swaps["march"]["phases"] > 0
