@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
             _run(["hipcc"] + HIPFLAGS + ["-c", src, "-o", obj], verbose)
         objs.append(obj)
     if force or _newer(LIB, objs):
-        _run(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-lm"], verbose)
+        _run(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-lm", "-lpthread"], verbose)
     build_cli(force=force, verbose=verbose)
     build_cython(force=force, verbose=verbose)
     return LIB

@@ -18,7 +18,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "polycap-hip.h"
@@ -594,6 +598,68 @@ __global__ void pc_images_transpose_kernel(const double *img, long long rec, lon
 
 /* =========================================================================== host side (C-ABI) */
 
+/* host threads that copy lists of memory pieces (image fetches: pinned staging -> the caller's planes) */
+struct pc_copy_piece { char *to; const char *from; size_t bytes; };
+
+class pc_copy_workers {
+public:
+	explicit pc_copy_workers(int n)
+	{
+		for (int t = 1; t < n; t++) threads_.emplace_back([this]() { loop(); });
+	}
+	~pc_copy_workers()
+	{
+		{ std::lock_guard<std::mutex> g(m_); stop_ = true; }
+		cv_work_.notify_all();
+		for (auto &t : threads_) t.join();
+	}
+	/* copies every piece; returns when all are done (the calling thread works too) */
+	void run(const std::vector<pc_copy_piece> &pieces)
+	{
+		{
+			std::lock_guard<std::mutex> g(m_);
+			pieces_ = &pieces; next_.store(0); busy_ = (int)threads_.size(); gen_++;
+		}
+		cv_work_.notify_all();
+		drain(pieces);
+		std::unique_lock<std::mutex> g(m_);
+		cv_done_.wait(g, [this]() { return busy_ == 0; });
+		pieces_ = nullptr;
+	}
+private:
+	void drain(const std::vector<pc_copy_piece> &pieces)
+	{
+		for (size_t j = next_.fetch_add(1); j < pieces.size(); j = next_.fetch_add(1))
+			memcpy(pieces[j].to, pieces[j].from, pieces[j].bytes);
+	}
+	void loop()
+	{
+		unsigned long seen = 0;
+		for (;;) {
+			const std::vector<pc_copy_piece> *p;
+			{
+				std::unique_lock<std::mutex> g(m_);
+				cv_work_.wait(g, [&]() { return stop_ || gen_ != seen; });
+				if (stop_) return;
+				seen = gen_; p = pieces_;
+			}
+			drain(*p);
+			{
+				std::lock_guard<std::mutex> g(m_);
+				if (--busy_ == 0) cv_done_.notify_all();
+			}
+		}
+	}
+	std::vector<std::thread> threads_;
+	std::mutex m_;
+	std::condition_variable cv_work_, cv_done_;
+	const std::vector<pc_copy_piece> *pieces_ = nullptr;
+	std::atomic<size_t> next_{0};
+	unsigned long gen_ = 0;
+	int busy_ = 0;
+	bool stop_ = false;
+};
+
 static thread_local std::string g_last_error;
 
 static int pc_fail(int code, const std::string &msg)
@@ -632,8 +698,12 @@ struct pc_hip_ctx {
 	pc_totals *d_totals = nullptr;         /* pc_totals + 2*nE u64 */
 	size_t totals_bytes = 0;
 	double *d_img = nullptr;               /* image records: n_slots x (17 + n_energies) doubles */
-	double *d_stage = nullptr;             /* SoA staging buffer for image fetches */
+	double *d_stage = nullptr;             /* SoA staging buffers for image fetches: two chunks on the device ... */
 	size_t stage_elems = 0;
+	double *h_stage = nullptr;             /* ... and two pinned chunks on the host */
+	size_t h_stage_elems = 0;
+	hipEvent_t ev_fetch[2] = {nullptr, nullptr};
+	int fetch_threads = 0;                 /* host threads that scatter a fetched chunk into the caller's planes; 0 = min(16, cores) */
 	long long img_slots = 0;
 	int img_valid = 0;
 	double *d_wscratch = nullptr;
@@ -797,6 +867,8 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->d_totals) (void)hipFree(ctx->d_totals);
 	if (ctx->d_img) (void)hipFree(ctx->d_img);
 	if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+	if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+	for (int k = 0; k < 2; k++) if (ctx->ev_fetch[k]) (void)hipEventDestroy(ctx->ev_fetch[k]);
 	if (ctx->d_wscratch) (void)hipFree(ctx->d_wscratch);
 	if (ctx->d_leak_frames) (void)hipFree(ctx->d_leak_frames);
 	if (ctx->d_leak_records) (void)hipFree(ctx->d_leak_records);
@@ -877,6 +949,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "block_size") { if (value < 64 || value > PC_BLOCK || (value % 64) != 0) return pc_fail(PC_HIP_ERR_INVALID, "block_size must be a multiple of 64 up to the compiled maximum"); ctx->block_size = (int)value; }
 	else if (n == "blocks_per_cu") { if (value < 1 || value > 8) return pc_fail(PC_HIP_ERR_INVALID, "blocks_per_cu must be in [1,8]"); ctx->blocks_per_cu = (int)value; }
 	else if (n == "lds_ec") ctx->lds_ec = value ? 1 : 0;
+	else if (n == "fetch_threads") { if (value < 0 || value > 256) return pc_fail(PC_HIP_ERR_INVALID, "fetch_threads must be in [0,256]"); ctx->fetch_threads = (int)value; }
 	else if (n == "pool") ctx->pool = value ? 1 : 0;
 	else if (n == "pool_refill") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "pool_refill must be in [1,64]"); ctx->pool_refill = (int)value; }
 	else if (n == "pool_event_min") { if (value < 1 || value > 128) return pc_fail(PC_HIP_ERR_INVALID, "pool_event_min must be in [1,128]"); ctx->pool_event_min = (int)value; }
@@ -1176,29 +1249,88 @@ int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, co
 		dst->pc_exit_coords[0], dst->pc_exit_coords[1], dst->pc_exit_coords[2],
 		dst->pc_exit_dir[0], dst->pc_exit_dir[1], dst->pc_exit_elecv[0], dst->pc_exit_elecv[1],
 		dst->pc_exit_nrefl, dst->pc_exit_dtravel };
-	/* records -> SoA planes on the device, in chunks of <= 256 MB, then plane-wise D2H copies */
-	size_t chunk = (size_t)(256u << 20) / (rec*sizeof(double));
-	if (chunk < 1024) chunk = 1024;
-	if (chunk > (size_t)count) chunk = (size_t)count;
-	if (ctx->stage_elems < chunk*rec) {
-		if (ctx->d_stage) PC_HIP_CHECK(hipFree(ctx->d_stage));
-		ctx->d_stage = nullptr; ctx->stage_elems = 0;
-		if (hipMalloc(&ctx->d_stage, chunk*rec*sizeof(double)) != hipSuccess)
-			return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_images: could not allocate the staging buffer");
-		ctx->stage_elems = chunk*rec;
-	}
-	for (size_t done = 0; done < (size_t)count; done += chunk) {
-		const size_t n = ((size_t)count - done < chunk) ? (size_t)count - done : chunk;
+	/* Small fetches: records -> SoA planes on the device, then plane-wise copies into the caller's (pageable) arrays. */
+	if ((size_t)count*rec*sizeof(double) <= ((size_t)8 << 20)) {
+		const size_t n = (size_t)count;
+		if (ctx->stage_elems < n*rec) {
+			if (ctx->d_stage) PC_HIP_CHECK(hipFree(ctx->d_stage));
+			ctx->d_stage = nullptr; ctx->stage_elems = 0;
+			if (hipMalloc(&ctx->d_stage, n*rec*sizeof(double)) != hipSuccess)
+				return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_images: could not allocate the staging buffer");
+			ctx->stage_elems = n*rec;
+		}
 		hipLaunchKernelGGL(pc_images_transpose_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, ctx->stream,
-		                   ctx->d_img, (long long)rec, (long long)(first + (int64_t)done), (long long)n, (int)ne, ctx->d_stage);
+		                   ctx->d_img, (long long)rec, (long long)first, (long long)n, (int)ne, ctx->d_stage);
 		PC_HIP_CHECK(hipGetLastError());
 		PC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		for (int k = 0; k < PC_N_PLANES; k++)
 			if (planes[k])
-				PC_HIP_CHECK(hipMemcpy((char *)planes[k] + done*sizeof(double), ctx->d_stage + (size_t)k*n, n*sizeof(double), hipMemcpyDeviceToHost));
+				PC_HIP_CHECK(hipMemcpy(planes[k], ctx->d_stage + (size_t)k*n, n*sizeof(double), hipMemcpyDeviceToHost));
 		if (dst->exit_coord_weights)
-			PC_HIP_CHECK(hipMemcpy(dst->exit_coord_weights + done*ne, ctx->d_stage + (size_t)PC_N_PLANES*n, n*ne*sizeof(double), hipMemcpyDeviceToHost));
+			PC_HIP_CHECK(hipMemcpy(dst->exit_coord_weights, ctx->d_stage + (size_t)PC_N_PLANES*n, n*ne*sizeof(double), hipMemcpyDeviceToHost));
+		return PC_HIP_OK;
 	}
+	/* Large fetches are a three-stage pipeline over chunks of <= 16 MB: transpose kernel (records -> SoA planes), one
+	 * asynchronous copy of the whole chunk into pinned host memory, and host threads that scatter the previous chunk into
+	 * the caller's planes while the next one is in flight (a plain hipMemcpy into pageable memory runs at 5-9 GB/s). */
+	size_t chunk = ((size_t)16 << 20) / (rec*sizeof(double));
+	if (chunk < 1024) chunk = 1024;
+	if (chunk > (size_t)count) chunk = (size_t)count;
+	if (ctx->stage_elems < 2*chunk*rec) {
+		if (ctx->d_stage) PC_HIP_CHECK(hipFree(ctx->d_stage));
+		ctx->d_stage = nullptr; ctx->stage_elems = 0;
+		if (hipMalloc(&ctx->d_stage, 2*chunk*rec*sizeof(double)) != hipSuccess)
+			return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_images: could not allocate the staging buffer");
+		ctx->stage_elems = 2*chunk*rec;
+	}
+	if (ctx->h_stage_elems < 2*chunk*rec) {
+		if (ctx->h_stage) PC_HIP_CHECK(hipHostFree(ctx->h_stage));
+		ctx->h_stage = nullptr; ctx->h_stage_elems = 0;
+		if (hipHostMalloc(&ctx->h_stage, 2*chunk*rec*sizeof(double), hipHostMallocDefault) != hipSuccess)
+			return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_images: could not allocate the pinned staging buffer");
+		ctx->h_stage_elems = 2*chunk*rec;
+	}
+	for (int k = 0; k < 2; k++)
+		if (!ctx->ev_fetch[k]) PC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fetch[k], hipEventDisableTiming));
+	int nthreads = ctx->fetch_threads;
+	if (nthreads <= 0) {
+		const unsigned hw = std::thread::hardware_concurrency();
+		nthreads = (int)(hw == 0 ? 4 : (hw > 16 ? 16 : hw));
+	}
+	/* scatter chunk [done, done + n) from the pinned buffer `src`: pieces of <= 1 MB handed to the worker threads */
+	pc_copy_workers workers(nthreads);
+	std::vector<pc_copy_piece> pieces;
+	auto scatter = [&](const double *src, size_t done, size_t n) {
+		pieces.clear();
+		const size_t step = (size_t)1 << 20;
+		auto add = [&](void *to, const double *from, size_t bytes) {
+			for (size_t o = 0; o < bytes; o += step)
+				pieces.push_back({(char *)to + o, (const char *)from + o, bytes - o < step ? bytes - o : step});
+		};
+		for (int k = 0; k < PC_N_PLANES; k++)
+			if (planes[k]) add((char *)planes[k] + done*sizeof(double), src + (size_t)k*n, n*sizeof(double));
+		if (dst->exit_coord_weights) add(dst->exit_coord_weights + done*ne, src + (size_t)PC_N_PLANES*n, n*ne*sizeof(double));
+		workers.run(pieces);
+	};
+	size_t prev_done = 0, prev_n = 0;
+	int c = 0;
+	for (size_t done = 0; done < (size_t)count; done += chunk, c++) {
+		const size_t n = ((size_t)count - done < chunk) ? (size_t)count - done : chunk;
+		const int b = c & 1;
+		double *d_buf = ctx->d_stage + (size_t)b*chunk*rec, *h_buf = ctx->h_stage + (size_t)b*chunk*rec;
+		hipLaunchKernelGGL(pc_images_transpose_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, ctx->stream,
+		                   ctx->d_img, (long long)rec, (long long)(first + (int64_t)done), (long long)n, (int)ne, d_buf);
+		PC_HIP_CHECK(hipGetLastError());
+		PC_HIP_CHECK(hipMemcpyAsync(h_buf, d_buf, n*rec*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		PC_HIP_CHECK(hipEventRecord(ctx->ev_fetch[b], ctx->stream));
+		if (c > 0) {
+			PC_HIP_CHECK(hipEventSynchronize(ctx->ev_fetch[b ^ 1]));
+			scatter(ctx->h_stage + (size_t)(b ^ 1)*chunk*rec, prev_done, prev_n);
+		}
+		prev_done = done; prev_n = n;
+	}
+	PC_HIP_CHECK(hipEventSynchronize(ctx->ev_fetch[(c - 1) & 1]));
+	scatter(ctx->h_stage + (size_t)((c - 1) & 1)*chunk*rec, prev_done, prev_n);
 	return PC_HIP_OK;
 }
 

@@ -139,6 +139,7 @@ POLYCAP_EXTERN const char *pc_hdf5_provider(void);
 
 /* result object construction (pc_transeff.c) */
 polycap_transmission_efficiencies *pc_transeff_alloc(polycap_source *source, size_t np, const char *caller, polycap_error **error);
+void pc_transeff_prefault(polycap_transmission_efficiencies *eff, size_t np);
 void pc_transeff_plane_pointers(polycap_transmission_efficiencies *eff, pc_hip_images *dst);
 void pc_transeff_finish(polycap_transmission_efficiencies *eff, const double *sum_weights, const int64_t counters[6]);
 int pc_transeff_fetch_leaks(polycap_transmission_efficiencies *eff, pc_hip_ctx *ctx);   /* returns a pc_hip_status */

@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 polycap_source *polycap_source_new(polycap_description *description, double d_source, double src_x, double src_y,
 	double src_sigx, double src_sigy, double src_shiftx, double src_shifty, double hor_pol,
@@ -316,6 +317,14 @@ static uint64_t pc_env_u64(const char *name, uint64_t fallback, int *present)
 	return (uint64_t)v;
 }
 
+/* POLYCAP_TIMING=1: stage times of polycap_source_get_transmission_efficiencies on stderr */
+static double pc_now_ms(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec*1e3 + ts.tv_nsec*1e-6;
+}
+
 polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(polycap_source *source, int max_threads, int n_photons,
 	bool leak_calc, polycap_progress_monitor *progress_monitor, polycap_error **error)
 {
@@ -353,6 +362,9 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 	}
 
 	const size_t ne = source->n_energies;
+	const int timing = getenv("POLYCAP_TIMING") != NULL;
+	double t_stage[8];
+	t_stage[0] = pc_now_ms();
 	polycap_transmission_efficiencies *eff = pc_transeff_alloc(source, (size_t)n_photons, "polycap_source_get_transmission_efficiencies", error);
 	double *sum_weights = malloc(sizeof(double)*ne);
 	if (eff == NULL || sum_weights == NULL) {
@@ -369,6 +381,7 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 		polycap_transmission_efficiencies_free(eff);
 		return NULL;
 	}
+	t_stage[1] = pc_now_ms();
 	int have_seed = 0;
 	uint64_t seed = pc_env_u64("POLYCAP_SEED", 0, &have_seed);
 	if (!have_seed)
@@ -379,8 +392,13 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 	int64_t counters[6] = {0, 0, 0, 0, 0, 0};
 	int status = leak_calc ? pc_hip_transmission_run_leak(ctx, seed, 0, n_photons, max_attempts, 1)
 	                       : pc_hip_transmission_run(ctx, seed, 0, n_photons, max_attempts, 1);
-	if (status == PC_HIP_OK)
+	t_stage[2] = pc_now_ms();
+	if (status == PC_HIP_OK) {
+		pc_transeff_prefault(eff, (size_t)n_photons);    /* the kernel is running: fault the result pages in meanwhile */
+		t_stage[3] = pc_now_ms();
 		status = pc_hip_transmission_wait(ctx, NULL);
+	}
+	t_stage[4] = pc_now_ms();
 	if (status == PC_HIP_OK)
 		status = pc_hip_transmission_totals(ctx, sum_weights, counters, NULL);
 	if (status == PC_HIP_OK) {
@@ -388,6 +406,10 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 		pc_transeff_plane_pointers(eff, &dst);
 		status = pc_hip_transmission_images(ctx, 0, n_photons, &dst);
 	}
+	t_stage[5] = pc_now_ms();
+	if (timing)
+		fprintf(stderr, "polycap timing [ms]: alloc+context %.1f, enqueue %.1f, prefault %.1f, wait %.1f, totals+images %.1f\n",
+			t_stage[1] - t_stage[0], t_stage[2] - t_stage[1], t_stage[3] - t_stage[2], t_stage[4] - t_stage[3], t_stage[5] - t_stage[4]);
 	if (status == PC_HIP_OK && leak_calc)
 		status = pc_transeff_fetch_leaks(eff, ctx);      /* reference :925-1032 */
 	if (status != PC_HIP_OK) {

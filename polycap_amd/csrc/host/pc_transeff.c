@@ -7,30 +7,74 @@
  * (extleak: coordinates, direction x/y, reflections, weights; intleak: the electric vector x/y as well).
  * The HDF5 writer (reference :38-780) lives in pc_hdf5.c.
  */
+#define _GNU_SOURCE
 #include "pc_private.h"
 
 #include <errno.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+/* Image planes: zeroed like calloc's.  Large planes are private anonymous mappings aligned to 2 MB and marked
+ * MADV_HUGEPAGE, so that faulting in 1.4 GB of results (1e7 photons) takes hundreds of huge-page faults instead of
+ * 350 000 small ones; a 64-byte header in front of every plane tells pc_plane_free how it was made. */
+#define PC_PLANE_MAGIC 0x706c616e65733031ull
+#define PC_HUGE_PAGE ((size_t)2 << 20)
+struct pc_plane_hdr { uint64_t magic; void *base; size_t len; uint64_t mapped; uint64_t pad[4]; };
+
+static void *pc_plane_calloc(size_t n, size_t size)
+{
+	if (size != 0 && n > (SIZE_MAX - 2*PC_HUGE_PAGE)/size) { errno = ENOMEM; return NULL; }
+	const size_t bytes = n*size;
+	struct pc_plane_hdr h = { PC_PLANE_MAGIC, NULL, 0, 0, {0, 0, 0, 0} };
+	char *user;
+	if (bytes >= 2*PC_HUGE_PAGE) {
+		h.len = bytes + sizeof(h) + PC_HUGE_PAGE;
+		h.base = mmap(NULL, h.len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+		if (h.base == MAP_FAILED) return NULL;
+		h.mapped = 1;
+		const uintptr_t first = (uintptr_t)h.base + sizeof(h);
+		user = (char *)((first + PC_HUGE_PAGE - 1) & ~(uintptr_t)(PC_HUGE_PAGE - 1));
+		(void)madvise(user, bytes, MADV_HUGEPAGE);     /* advisory: without THP the mapping is simply small pages */
+	} else {
+		h.base = calloc(1, bytes + sizeof(h));
+		if (h.base == NULL) return NULL;
+		user = (char *)h.base + sizeof(h);
+	}
+	memcpy(user - sizeof(h), &h, sizeof(h));
+	return user;
+}
+
+static void pc_plane_free(void *plane)
+{
+	if (plane == NULL) return;
+	struct pc_plane_hdr h;
+	memcpy(&h, (char *)plane - sizeof(h), sizeof(h));
+	if (h.magic != PC_PLANE_MAGIC) return;      /* not one of ours: leave it alone rather than guess */
+	if (h.mapped) munmap(h.base, h.len);
+	else free(h.base);
+}
 
 static void pc_images_free(struct _polycap_images *images)
 {
 	if (images == NULL)
 		return;
 	for (int k = 0; k < 2; k++) {
-		free(images->src_start_coords[k]);
-		free(images->pc_start_coords[k]);
-		free(images->pc_start_dir[k]);
-		free(images->pc_start_elecv[k]);
-		free(images->pc_exit_dir[k]);
-		free(images->pc_exit_elecv[k]);
+		pc_plane_free(images->src_start_coords[k]);
+		pc_plane_free(images->pc_start_coords[k]);
+		pc_plane_free(images->pc_start_dir[k]);
+		pc_plane_free(images->pc_start_elecv[k]);
+		pc_plane_free(images->pc_exit_dir[k]);
+		pc_plane_free(images->pc_exit_elecv[k]);
 	}
 	for (int k = 0; k < 3; k++)
-		free(images->pc_exit_coords[k]);
-	free(images->pc_exit_nrefl);
-	free(images->pc_exit_dtravel);
-	free(images->exit_coord_weights);
+		pc_plane_free(images->pc_exit_coords[k]);
+	pc_plane_free(images->pc_exit_nrefl);
+	pc_plane_free(images->pc_exit_dtravel);
+	pc_plane_free(images->exit_coord_weights);
 	for (int k = 0; k < 3; k++) {
 		free(images->extleak_coords[k]);
 		free(images->intleak_coords[k]);
@@ -78,11 +122,11 @@ polycap_transmission_efficiencies *pc_transeff_alloc(polycap_source *source, siz
 			&im->pc_exit_dir[0], &im->pc_exit_dir[1], &im->pc_exit_elecv[0], &im->pc_exit_elecv[1], &im->pc_exit_dtravel };
 		alloc_ok = (eff->energies != NULL && eff->efficiencies != NULL);
 		for (size_t k = 0; k < sizeof(planes)/sizeof(planes[0]); k++) {
-			*planes[k] = calloc(nalloc, sizeof(double));
+			*planes[k] = pc_plane_calloc(nalloc, sizeof(double));
 			alloc_ok = alloc_ok && (*planes[k] != NULL);
 		}
-		im->pc_exit_nrefl = calloc(nalloc, sizeof(int64_t));
-		im->exit_coord_weights = calloc(nalloc*ne, sizeof(double));
+		im->pc_exit_nrefl = pc_plane_calloc(nalloc, sizeof(int64_t));
+		im->exit_coord_weights = pc_plane_calloc(nalloc*ne, sizeof(double));
 		alloc_ok = alloc_ok && im->pc_exit_nrefl != NULL && im->exit_coord_weights != NULL;
 	}
 	if (!alloc_ok) {
@@ -113,6 +157,62 @@ void pc_transeff_plane_pointers(polycap_transmission_efficiencies *eff, pc_hip_i
 	dst->pc_exit_nrefl = im->pc_exit_nrefl;
 	dst->pc_exit_dtravel = im->pc_exit_dtravel;
 	dst->exit_coord_weights = im->exit_coord_weights;
+}
+
+/* Touch every page of the image planes from several host threads.  The planes come zeroed from calloc, i.e. as untouched
+ * mappings: their first write costs a page fault + a zeroed page each (350 000 of them for 1e7 photons), which the copy
+ * of the results would otherwise pay on one thread.  polycap_source_get_transmission_efficiencies calls this while the
+ * GPU traces, so the faults are off the critical path. */
+struct pc_touch_job { char *base; size_t bytes; };
+struct pc_touch_arg { const struct pc_touch_job *jobs; int njobs, tid, nthreads; };
+
+static void *pc_touch_thread(void *p)
+{
+	const struct pc_touch_arg *a = p;
+	const size_t page = 4096;
+	for (int j = 0; j < a->njobs; j++) {
+		const size_t npages = (a->jobs[j].bytes + page - 1)/page;
+		const size_t lo = npages*(size_t)a->tid/(size_t)a->nthreads, hi = npages*(size_t)(a->tid + 1)/(size_t)a->nthreads;
+		volatile char *b = a->jobs[j].base;
+		for (size_t k = lo; k < hi; k++)
+			b[k*page] = 0;
+	}
+	return NULL;
+}
+
+void pc_transeff_prefault(polycap_transmission_efficiencies *eff, size_t np)
+{
+	if (eff == NULL || eff->images == NULL || np*sizeof(double) < ((size_t)4 << 20))
+		return;
+	pc_hip_images d;
+	pc_transeff_plane_pointers(eff, &d);
+	struct pc_touch_job jobs[18];
+	int nj = 0;
+	void *planes[] = { d.src_start_coords[0], d.src_start_coords[1], d.pc_start_coords[0], d.pc_start_coords[1],
+		d.pc_start_dir[0], d.pc_start_dir[1], d.pc_start_elecv[0], d.pc_start_elecv[1],
+		d.pc_exit_coords[0], d.pc_exit_coords[1], d.pc_exit_coords[2], d.pc_exit_dir[0], d.pc_exit_dir[1],
+		d.pc_exit_elecv[0], d.pc_exit_elecv[1], d.pc_exit_nrefl, d.pc_exit_dtravel };
+	for (size_t k = 0; k < sizeof(planes)/sizeof(planes[0]); k++)
+		if (planes[k] != NULL) { jobs[nj].base = planes[k]; jobs[nj].bytes = np*sizeof(double); nj++; }
+	if (d.exit_coord_weights != NULL) { jobs[nj].base = (char *)d.exit_coord_weights; jobs[nj].bytes = np*eff->n_energies*sizeof(double); nj++; }
+	long cores = sysconf(_SC_NPROCESSORS_ONLN);
+	int nt = (int)(cores < 1 ? 1 : (cores > 16 ? 16 : cores));
+	pthread_t th[16];
+	struct pc_touch_arg args[16];
+	int started = 0;
+	for (int t = 0; t < nt; t++) {
+		args[t].jobs = jobs; args[t].njobs = nj; args[t].tid = t; args[t].nthreads = nt;
+		if (t > 0 && pthread_create(&th[t], NULL, pc_touch_thread, &args[t]) != 0) {
+			/* no thread: this slice is touched by the caller below */
+			th[t] = 0;
+			pc_touch_thread(&args[t]);
+			continue;
+		}
+		if (t > 0) started |= 1 << t;
+	}
+	pc_touch_thread(&args[0]);
+	for (int t = 1; t < nt; t++)
+		if (started & (1 << t)) pthread_join(th[t], NULL);
 }
 
 /* totals -> open area, counts and efficiencies (reference: src/polycap-source.c:1061-1076) */

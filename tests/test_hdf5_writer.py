@@ -185,3 +185,24 @@ def test_file_layout_units_and_values(api, tmp_path):
     cap = _read(path, "/Input/Cap_Shape", tmp).reshape(2, nmax)
     assert np.array_equal(shape[0], cap[0]) and np.all(np.diff(shape[0]) > 0) and shape[0][0] == 0.
     assert np.all(cap[1] < shape[1]) and np.all(cap[1] > 0)
+
+
+def test_large_planes_use_the_mapped_allocator(api):
+    """Planes of 4 MB and more are 2 MB-aligned anonymous mappings (huge-page advice) with a header in front instead of
+    calloc blocks (pc_transeff.c): same contents, same getters, freed without leaks or crashes; mixed sizes in one object."""
+    src0 = api.Source.new_from_file(DECK)
+    prof = api.Profile(api.Profile.ELLIPSOIDAL, 9., 0.2065, 0.0585, 0.00035, 9.9153e-05, 1000., 0.5)
+    desc = api.Description(prof, 0., 200000, {"O": 53.0, "Si": 47.0}, 2.23)
+    one = api.Source(desc, 2000., 0.2065, 0.2065, 0., 0., 0., 0., 0., np.array([10.0]))
+    rng = np.random.default_rng(6)
+    for src, n, ne in ((one, 600000, 1), (src0, 2500, NE)):       # every plane mapped / only the weights plane mapped
+        images = rng.uniform(-1, 1, size=(n, 17)) * 0.1
+        images[:, 15] = rng.integers(0, 40, size=n)
+        weights = rng.uniform(0, 1, size=(n, ne))
+        counters = np.array([n, 11, 5, int(images[:, 15].sum()), 0, 1], dtype=np.int64)
+        for _ in range(2):
+            eff = api.TransmissionEfficiencies.from_totals(src, weights.sum(axis=0), counters, images, weights)
+            assert np.array_equal(eff.exit_weights, weights)
+            assert np.array_equal(eff.d_travel, images[:, 16])
+            assert np.array_equal(eff.n_refl, images[:, 15].astype(np.int64))
+            del eff
