@@ -39,7 +39,9 @@
 #define PC_MARCH_UNROLL 4      /* march steps between two ballots of the burst loop */
 #endif
 #define PC_KE 5                /* energies per lane whose weights are in flight together in a cooperative sweep */
+#ifndef PC_CHUNK
 #define PC_CHUNK 128           /* slots a wave takes from the global counter at a time */
+#endif
 #define PC_FIX_SCALE 4611686018427387904.0 /* 2^62 */
 #ifndef PC_MIN_WAVES_NE0
 #define PC_MIN_WAVES_NE0 2     /* the any-n_energies kernel: 256 VGPRs (it spills 470 B per lane at 128), 8 waves per CU */
@@ -51,7 +53,7 @@
 /* --------------------------------------------------------------------------- kernel arguments */
 
 /* Per-exit-photon image record in HBM: one contiguous record per slot (17 + n_energies doubles) so that a lane
- * writes whole 64/128-byte segments instead of 18 scattered 8-byte words; pc_images_transpose_kernel turns a
+ * writes whole 64/128-byte segments instead of 18 scattered 8-byte words; the host side of the fetch (pc_hip_transmission_images) turns a
  * range of records into the reference's SoA planes (struct _polycap_images) when the host asks for them.
  * Field order = pc_hip_images / the reference's plane order. */
 enum { PC_F_SRCX = 0, PC_F_SRCY, PC_F_STARTX, PC_F_STARTY, PC_F_SDIRX, PC_F_SDIRY, PC_F_SEVX, PC_F_SEVY,
@@ -79,6 +81,7 @@ struct pc_kargs {
 	int event_threshold;
 	int march_burst;
 	pc_totals *totals;
+	unsigned long long *work;     /* the launch's work counter (relative slot index handed out next) */
 	unsigned long long *sumw;     /* 2*n_energies */
 	double *img;                  /* [n_slots][17 + n_energies] records, or NULL */
 	int new_threshold;
@@ -464,7 +467,7 @@ pc_trace_kernel(pc_kargs a)
 						/* top up: take what is left of the old chunk first, then a fresh chunk */
 						long long have = chunk_end - chunk_next;
 						long long base_new = 0;
-						if (lane == 0) base_new = (long long)atomicAdd(&a.totals->next_slot, (unsigned long long)PC_CHUNK);
+						if (lane == 0) base_new = (long long)atomicAdd(a.work, (unsigned long long)PC_CHUNK);
 						base_new = __shfl(base_new, 0, PC_WAVE);
 						const int rank = __popcll(need & ((1ull << lane) - 1ull));
 						if (state == LS_NEED_SLOT) {
@@ -582,24 +585,8 @@ __global__ void pc_sample_kernel(pc_params pm, unsigned long long seed, long lon
 	o[6] = s.ex; o[7] = s.ey; o[8] = s.ez; o[9] = s.srcx; o[10] = s.srcy; o[11] = 0.;
 }
 
-/* image records [first, first+count) -> SoA planes (plane k at out + k*count; weights row-major behind them) */
-__global__ void pc_images_transpose_kernel(const double *img, long long rec, long long first, long long count, int ne, double *out)
-{
-	long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= count) return;
-	const double *r = img + (first + j)*rec;
-#pragma unroll
-	for (int k = 0; k < PC_N_FIELDS; k++)
-		out[(long long)k*count + j] = r[k];
-	double *w = out + (long long)PC_N_FIELDS*count + j*ne;
-	for (int e = 0; e < ne; e++)
-		w[e] = r[PC_F_WEIGHTS + e];
-}
-
-/* =========================================================================== host side (C-ABI) */
-
-/* host threads that copy lists of memory pieces (image fetches: pinned staging -> the caller's planes) */
-struct pc_copy_piece { char *to; const char *from; size_t bytes; };
+/* host threads that turn fetched image records (AoS, `rec` doubles per slot) into the caller's SoA planes */
+struct pc_copy_piece { const double *from; size_t slot; size_t n; };      /* n records at `from` belong to slots [slot, slot + n) */
 
 class pc_copy_workers {
 public:
@@ -613,37 +600,59 @@ public:
 		cv_work_.notify_all();
 		for (auto &t : threads_) t.join();
 	}
-	/* copies every piece; returns when all are done (the calling thread works too) */
-	void run(const std::vector<pc_copy_piece> &pieces)
+	/* scatters every piece; returns when all are done (the calling thread works too) */
+	void run(const std::vector<pc_copy_piece> &pieces, void *const *planes, double *weights, size_t rec, size_t ne)
 	{
 		{
 			std::lock_guard<std::mutex> g(m_);
-			pieces_ = &pieces; next_.store(0); busy_ = (int)threads_.size(); gen_++;
+			pieces_ = &pieces; planes_ = planes; weights_ = weights; rec_ = rec; ne_ = ne;
+			next_.store(0); busy_ = (int)threads_.size(); gen_++;
 		}
 		cv_work_.notify_all();
-		drain(pieces);
+		drain();
 		std::unique_lock<std::mutex> g(m_);
 		cv_done_.wait(g, [this]() { return busy_ == 0; });
 		pieces_ = nullptr;
 	}
 private:
-	void drain(const std::vector<pc_copy_piece> &pieces)
+	void drain()
 	{
-		for (size_t j = next_.fetch_add(1); j < pieces.size(); j = next_.fetch_add(1))
-			memcpy(pieces[j].to, pieces[j].from, pieces[j].bytes);
+		const std::vector<pc_copy_piece> &pieces = *pieces_;
+		const size_t rec = rec_, ne = ne_;
+		const size_t nplanes = rec - ne;
+		for (size_t j = next_.fetch_add(1); j < pieces.size(); j = next_.fetch_add(1)) {
+			const pc_copy_piece &p = pieces[j];
+			/* plane by plane: strided reads of a piece that fits the cache, contiguous writes (8-byte words: the
+			 * reflection count is an int64 plane) */
+			for (size_t k = 0; k < nplanes; k++) {
+				if (!planes_[k]) continue;
+				double *to = (double *)planes_[k] + p.slot;
+				const double *from = p.from + k;
+				for (size_t i = 0; i < p.n; i++) to[i] = from[i*rec];
+			}
+			if (weights_) {
+				if (ne == 1) {
+					double *to = weights_ + p.slot;
+					const double *from = p.from + nplanes;
+					for (size_t i = 0; i < p.n; i++) to[i] = from[i*rec];
+				} else {
+					for (size_t i = 0; i < p.n; i++)
+						memcpy(weights_ + (p.slot + i)*ne, p.from + i*rec + nplanes, ne*sizeof(double));
+				}
+			}
+		}
 	}
 	void loop()
 	{
 		unsigned long seen = 0;
 		for (;;) {
-			const std::vector<pc_copy_piece> *p;
 			{
 				std::unique_lock<std::mutex> g(m_);
 				cv_work_.wait(g, [&]() { return stop_ || gen_ != seen; });
 				if (stop_) return;
-				seen = gen_; p = pieces_;
+				seen = gen_;
 			}
-			drain(*p);
+			drain();
 			{
 				std::lock_guard<std::mutex> g(m_);
 				if (--busy_ == 0) cv_done_.notify_all();
@@ -654,6 +663,9 @@ private:
 	std::mutex m_;
 	std::condition_variable cv_work_, cv_done_;
 	const std::vector<pc_copy_piece> *pieces_ = nullptr;
+	void *const *planes_ = nullptr;
+	double *weights_ = nullptr;
+	size_t rec_ = 0, ne_ = 0;
 	std::atomic<size_t> next_{0};
 	unsigned long gen_ = 0;
 	int busy_ = 0;
@@ -670,6 +682,8 @@ static int pc_fail(int code, const std::string &msg)
 
 #define PC_HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) \
 	return pc_fail(PC_HIP_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+
+#define PC_MAX_PARTS 16
 
 struct pc_hip_ctx {
 	int device = 0;
@@ -698,11 +712,20 @@ struct pc_hip_ctx {
 	pc_totals *d_totals = nullptr;         /* pc_totals + 2*nE u64 */
 	size_t totals_bytes = 0;
 	double *d_img = nullptr;               /* image records: n_slots x (17 + n_energies) doubles */
-	double *d_stage = nullptr;             /* SoA staging buffers for image fetches: two chunks on the device ... */
-	size_t stage_elems = 0;
-	double *h_stage = nullptr;             /* ... and two pinned chunks on the host */
+	double *h_stage = nullptr;             /* image fetches: two pinned chunks of records on the host */
 	size_t h_stage_elems = 0;
 	hipEvent_t ev_fetch[2] = {nullptr, nullptr};
+	hipStream_t fetch_stream = nullptr;    /* copies of finished parts run beside the kernel of the next part */
+	hipStream_t stream2 = nullptr;         /* odd parts: a part's first workgroups start as the previous part's last ones leave */
+	unsigned long long *d_work = nullptr;  /* one work counter per part */
+	hipEvent_t ev_sync = nullptr;
+	/* a transmission run can be cut into parts (kernel launches over consecutive slot ranges, same totals): the images of
+	 * a finished part are fetched while the next part is traced */
+	int run_parts = 1;
+	int n_parts = 1;
+	long long part_end[PC_MAX_PARTS] = {0};
+	hipEvent_t ev_part[PC_MAX_PARTS] = {nullptr};
+	bool rec_ev0 = true, rec_ev1 = true;
 	int fetch_threads = 0;                 /* host threads that scatter a fetched chunk into the caller's planes; 0 = min(16, cores) */
 	long long img_slots = 0;
 	int img_valid = 0;
@@ -750,6 +773,7 @@ static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
 	a.march_burst = ctx->march_burst;
 	a.pool_refill = ctx->pool_refill;
 	a.totals = ctx->d_totals;
+	a.work = &ctx->d_totals->next_slot;
 	a.sumw = (unsigned long long *)(ctx->d_totals + 1);
 }
 
@@ -806,10 +830,10 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		a.event_threshold = ctx->pool_march_min;
 		a.pool_event_min = ctx->pool_event_min;
 		a.new_threshold = ctx->pool_new_min;
-		PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+		if (ctx->rec_ev0) PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
 		pc_launch_pool<MODE>(ctx, a, grid);
 		PC_HIP_CHECK(hipGetLastError());
-		PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+		if (ctx->rec_ev1) PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
 		return PC_HIP_OK;
 	}
 	long long max_blocks = (long long)ctx->n_cu * ((kne == 0) ? 1 : ctx->blocks_per_cu);
@@ -829,11 +853,11 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		}
 		a.wscratch = ctx->d_wscratch;
 	}
-	PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+	if (ctx->rec_ev0) PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
 	int st = (kne == 1) ? pc_launch_one<1, MODE>(ctx, a, grid) : (kne == 4) ? pc_launch_one<4, MODE>(ctx, a, grid)
 	       : (kne == 8) ? pc_launch_one<8, MODE>(ctx, a, grid) : pc_launch_one<0, MODE>(ctx, a, grid);
 	if (st) return st;
-	PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+	if (ctx->rec_ev1) PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
 	return PC_HIP_OK;
 }
 
@@ -866,9 +890,13 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->d_ftables) (void)hipFree(ctx->d_ftables);
 	if (ctx->d_totals) (void)hipFree(ctx->d_totals);
 	if (ctx->d_img) (void)hipFree(ctx->d_img);
-	if (ctx->d_stage) (void)hipFree(ctx->d_stage);
 	if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
 	for (int k = 0; k < 2; k++) if (ctx->ev_fetch[k]) (void)hipEventDestroy(ctx->ev_fetch[k]);
+	for (int k = 0; k < PC_MAX_PARTS; k++) if (ctx->ev_part[k]) (void)hipEventDestroy(ctx->ev_part[k]);
+	if (ctx->fetch_stream) (void)hipStreamDestroy(ctx->fetch_stream);
+	if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+	if (ctx->d_work) (void)hipFree(ctx->d_work);
+	if (ctx->ev_sync) (void)hipEventDestroy(ctx->ev_sync);
 	if (ctx->d_wscratch) (void)hipFree(ctx->d_wscratch);
 	if (ctx->d_leak_frames) (void)hipFree(ctx->d_leak_frames);
 	if (ctx->d_leak_records) (void)hipFree(ctx->d_leak_records);
@@ -949,6 +977,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "block_size") { if (value < 64 || value > PC_BLOCK || (value % 64) != 0) return pc_fail(PC_HIP_ERR_INVALID, "block_size must be a multiple of 64 up to the compiled maximum"); ctx->block_size = (int)value; }
 	else if (n == "blocks_per_cu") { if (value < 1 || value > 8) return pc_fail(PC_HIP_ERR_INVALID, "blocks_per_cu must be in [1,8]"); ctx->blocks_per_cu = (int)value; }
 	else if (n == "lds_ec") ctx->lds_ec = value ? 1 : 0;
+	else if (n == "run_parts") { if (value < 1 || value > PC_MAX_PARTS) return pc_fail(PC_HIP_ERR_INVALID, "run_parts must be in [1,16]"); ctx->run_parts = (int)value; }
 	else if (n == "fetch_threads") { if (value < 0 || value > 256) return pc_fail(PC_HIP_ERR_INVALID, "fetch_threads must be in [0,256]"); ctx->fetch_threads = (int)value; }
 	else if (n == "pool") ctx->pool = value ? 1 : 0;
 	else if (n == "pool_refill") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "pool_refill must be in [1,64]"); ctx->pool_refill = (int)value; }
@@ -1079,6 +1108,17 @@ int pc_hip_sample_photons(pc_hip_ctx *ctx, uint64_t seed, int64_t n, const int64
 	return status;
 }
 
+/* First slot of part k of `parts`.  The fetch of the images can start when the first part is done and has the last part
+ * left when the kernel ends, so with three or more parts the first and the last are half the size of the others. */
+static long long pc_part_begin(long long n_slots, int parts, int k)
+{
+	if (k <= 0) return 0;
+	if (k >= parts) return n_slots;
+	if (parts < 3) return n_slots*k/parts;
+	const double unit = 1.0/(double)(parts - 1);           /* 1/2 + (parts - 2) + 1/2 units */
+	return (long long)((double)n_slots*unit*((double)k - 0.5));
+}
+
 /* image planes: 17 double-sized planes of n_slots entries followed by the weights plane */
 static const int PC_N_PLANES = 17;
 
@@ -1104,9 +1144,57 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 		a.img = ctx->d_img;
 	}
 	PC_HIP_CHECK(hipMemsetAsync(ctx->d_totals, 0, ctx->totals_bytes, ctx->stream));
-	a.seed = seed; a.slot0 = slot0; a.n_slots = n_slots; a.max_attempts = max_attempts; a.keep_images = keep_images ? 1 : 0;
-	int status = ctx->host.pm.generic_src ? pc_launch_kernel<PC_MODE_SRC_GENERIC>(ctx, a, n_slots)
-	                                        : pc_launch_kernel<PC_MODE_SRC_CIRCULAR>(ctx, a, n_slots);
+	a.seed = seed; a.max_attempts = max_attempts; a.keep_images = keep_images ? 1 : 0;
+	/* parts: consecutive slot ranges traced by consecutive launches into the same totals and image records (a photon
+	 * depends on its global slot number only, so the result does not depend on the cut) */
+	int parts = (keep_images && ctx->run_parts > 1) ? ctx->run_parts : 1;
+	if (parts > PC_MAX_PARTS) parts = PC_MAX_PARTS;
+	if ((long long)parts > n_slots / 65536) parts = (int)(n_slots / 65536);
+	if (parts < 1) parts = 1;
+	ctx->n_parts = parts;
+	const size_t rec = (size_t)PC_N_PLANES + ne;
+	int status = PC_HIP_OK;
+	hipStream_t main_stream = ctx->stream;
+	struct restore_ctx {          /* the launch helpers read the stream and the event flags from the context */
+		pc_hip_ctx *c; hipStream_t s;
+		~restore_ctx() { c->stream = s; c->rec_ev0 = c->rec_ev1 = true; }
+	} restore{ctx, main_stream};
+	if (parts > 1) {
+		/* Parts alternate between two streams.  Every launch fills the device with persistent workgroups, so the
+		 * workgroups of part k+1 start exactly as those of part k run out of slots and leave: the tail of one part (its
+		 * longest photons) is covered by the head of the next, and the parts still finish in order. */
+		if (!ctx->stream2) PC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+		if (!ctx->ev_sync) PC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_sync, hipEventDisableTiming));
+		if (!ctx->d_work) PC_HIP_CHECK(hipMalloc(&ctx->d_work, PC_MAX_PARTS*sizeof(unsigned long long)));
+		PC_HIP_CHECK(hipMemsetAsync(ctx->d_work, 0, PC_MAX_PARTS*sizeof(unsigned long long), main_stream));
+		PC_HIP_CHECK(hipEventRecord(ctx->ev0, main_stream));
+		PC_HIP_CHECK(hipEventRecord(ctx->ev_sync, main_stream));
+		PC_HIP_CHECK(hipStreamWaitEvent(ctx->stream2, ctx->ev_sync, 0));     /* totals and counters are zero */
+		ctx->rec_ev0 = ctx->rec_ev1 = false;
+	}
+	for (int k = 0; k < parts && status == PC_HIP_OK; k++) {
+		const long long lo = pc_part_begin(n_slots, parts, k), hi = pc_part_begin(n_slots, parts, k + 1);
+		a.slot0 = slot0 + lo; a.n_slots = hi - lo;
+		a.img = keep_images ? ctx->d_img + (size_t)lo*rec : nullptr;
+		if (parts > 1) {
+			a.work = ctx->d_work + k;
+			ctx->stream = (k & 1) ? ctx->stream2 : main_stream;
+		}
+		status = ctx->host.pm.generic_src ? pc_launch_kernel<PC_MODE_SRC_GENERIC>(ctx, a, hi - lo)
+		                                  : pc_launch_kernel<PC_MODE_SRC_CIRCULAR>(ctx, a, hi - lo);
+		ctx->part_end[k] = hi;
+		if (status == PC_HIP_OK && parts > 1) {
+			if (!ctx->ev_part[k]) PC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_part[k], hipEventDisableTiming));
+			PC_HIP_CHECK(hipEventRecord(ctx->ev_part[k], ctx->stream));
+		}
+	}
+	ctx->stream = main_stream;
+	if (parts > 1 && status == PC_HIP_OK) {
+		/* the main stream ends after every part: wait() synchronises it, and the kernel time runs to here */
+		for (int k = 0; k < parts; k++)
+			if (k & 1) PC_HIP_CHECK(hipStreamWaitEvent(main_stream, ctx->ev_part[k], 0));
+		PC_HIP_CHECK(hipEventRecord(ctx->ev1, main_stream));
+	}
 	if (status) return status;
 	ctx->run_slots = n_slots;
 	ctx->run_pending = 1;
@@ -1130,6 +1218,7 @@ int pc_hip_transmission_run_leak(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, 
 			return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_run_leak: could not allocate the image planes; use keep_images=0");
 		ctx->img_slots = n_slots;
 	}
+	ctx->n_parts = 1;
 	ctx->leak_seed = seed; ctx->leak_slot0 = slot0; ctx->leak_n_slots = n_slots;
 	ctx->leak_max_attempts = max_attempts; ctx->leak_keep_images = keep_images ? 1 : 0;
 	ctx->leak_capacity_used = ctx->leak_capacity > 0 ? ctx->leak_capacity : std::max<long long>(65536, 16*n_slots);
@@ -1239,9 +1328,13 @@ int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, co
 	if (!ctx || !dst) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: NULL argument");
 	if (!ctx->img_valid) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: the last run kept no images");
 	if (first < 0 || count < 0 || first + count > ctx->run_slots) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: slot range out of bounds");
-	int st = pc_hip_transmission_wait(ctx, nullptr);
-	if (st) return st;
+	/* a leak run is complete (and possibly repeated) only after wait(); a plain run is fetched part by part below */
+	if (ctx->leak_pending || ctx->n_parts <= 1) {
+		int st = pc_hip_transmission_wait(ctx, nullptr);
+		if (st) return st;
+	}
 	if (count == 0) return PC_HIP_OK;
+	PC_HIP_CHECK(hipSetDevice(ctx->device));
 	const size_t ne = (size_t)ctx->host.pm.n_energies, rec = (size_t)PC_N_PLANES + ne;
 	void *planes[PC_N_PLANES] = {
 		dst->src_start_coords[0], dst->src_start_coords[1], dst->pc_start_coords[0], dst->pc_start_coords[1],
@@ -1249,40 +1342,13 @@ int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, co
 		dst->pc_exit_coords[0], dst->pc_exit_coords[1], dst->pc_exit_coords[2],
 		dst->pc_exit_dir[0], dst->pc_exit_dir[1], dst->pc_exit_elecv[0], dst->pc_exit_elecv[1],
 		dst->pc_exit_nrefl, dst->pc_exit_dtravel };
-	/* Small fetches: records -> SoA planes on the device, then plane-wise copies into the caller's (pageable) arrays. */
-	if ((size_t)count*rec*sizeof(double) <= ((size_t)8 << 20)) {
-		const size_t n = (size_t)count;
-		if (ctx->stage_elems < n*rec) {
-			if (ctx->d_stage) PC_HIP_CHECK(hipFree(ctx->d_stage));
-			ctx->d_stage = nullptr; ctx->stage_elems = 0;
-			if (hipMalloc(&ctx->d_stage, n*rec*sizeof(double)) != hipSuccess)
-				return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_images: could not allocate the staging buffer");
-			ctx->stage_elems = n*rec;
-		}
-		hipLaunchKernelGGL(pc_images_transpose_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, ctx->stream,
-		                   ctx->d_img, (long long)rec, (long long)first, (long long)n, (int)ne, ctx->d_stage);
-		PC_HIP_CHECK(hipGetLastError());
-		PC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-		for (int k = 0; k < PC_N_PLANES; k++)
-			if (planes[k])
-				PC_HIP_CHECK(hipMemcpy(planes[k], ctx->d_stage + (size_t)k*n, n*sizeof(double), hipMemcpyDeviceToHost));
-		if (dst->exit_coord_weights)
-			PC_HIP_CHECK(hipMemcpy(dst->exit_coord_weights, ctx->d_stage + (size_t)PC_N_PLANES*n, n*ne*sizeof(double), hipMemcpyDeviceToHost));
-		return PC_HIP_OK;
-	}
-	/* Large fetches are a three-stage pipeline over chunks of <= 16 MB: transpose kernel (records -> SoA planes), one
-	 * asynchronous copy of the whole chunk into pinned host memory, and host threads that scatter the previous chunk into
-	 * the caller's planes while the next one is in flight (a plain hipMemcpy into pageable memory runs at 5-9 GB/s). */
+	/* Pipeline over chunks of <= 16 MB of records: one asynchronous copy (DMA engine, no compute units) of the chunk into
+	 * pinned host memory, then host threads turn the records of the previous chunk into the caller's SoA planes while the
+	 * next one is in flight.  The copies run on their own stream and wait only for the part of the run that holds the
+	 * chunk, so they overlap the kernel of the following parts. */
 	size_t chunk = ((size_t)16 << 20) / (rec*sizeof(double));
-	if (chunk < 1024) chunk = 1024;
+	if (chunk < 256) chunk = 256;
 	if (chunk > (size_t)count) chunk = (size_t)count;
-	if (ctx->stage_elems < 2*chunk*rec) {
-		if (ctx->d_stage) PC_HIP_CHECK(hipFree(ctx->d_stage));
-		ctx->d_stage = nullptr; ctx->stage_elems = 0;
-		if (hipMalloc(&ctx->d_stage, 2*chunk*rec*sizeof(double)) != hipSuccess)
-			return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_images: could not allocate the staging buffer");
-		ctx->stage_elems = 2*chunk*rec;
-	}
 	if (ctx->h_stage_elems < 2*chunk*rec) {
 		if (ctx->h_stage) PC_HIP_CHECK(hipHostFree(ctx->h_stage));
 		ctx->h_stage = nullptr; ctx->h_stage_elems = 0;
@@ -1292,37 +1358,37 @@ int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, co
 	}
 	for (int k = 0; k < 2; k++)
 		if (!ctx->ev_fetch[k]) PC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fetch[k], hipEventDisableTiming));
+	if (!ctx->fetch_stream) PC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking));
 	int nthreads = ctx->fetch_threads;
 	if (nthreads <= 0) {
 		const unsigned hw = std::thread::hardware_concurrency();
 		nthreads = (int)(hw == 0 ? 4 : (hw > 16 ? 16 : hw));
 	}
-	/* scatter chunk [done, done + n) from the pinned buffer `src`: pieces of <= 1 MB handed to the worker threads */
+	if ((size_t)count*rec*sizeof(double) < ((size_t)4 << 20)) nthreads = 1;
 	pc_copy_workers workers(nthreads);
 	std::vector<pc_copy_piece> pieces;
+	/* records [done, done + n) in the pinned buffer `src` -> planes: pieces of 4096 records for the worker threads */
 	auto scatter = [&](const double *src, size_t done, size_t n) {
 		pieces.clear();
-		const size_t step = (size_t)1 << 20;
-		auto add = [&](void *to, const double *from, size_t bytes) {
-			for (size_t o = 0; o < bytes; o += step)
-				pieces.push_back({(char *)to + o, (const char *)from + o, bytes - o < step ? bytes - o : step});
-		};
-		for (int k = 0; k < PC_N_PLANES; k++)
-			if (planes[k]) add((char *)planes[k] + done*sizeof(double), src + (size_t)k*n, n*sizeof(double));
-		if (dst->exit_coord_weights) add(dst->exit_coord_weights + done*ne, src + (size_t)PC_N_PLANES*n, n*ne*sizeof(double));
-		workers.run(pieces);
+		for (size_t o = 0; o < n; o += 4096)
+			pieces.push_back({src + o*rec, done + o, n - o < 4096 ? n - o : 4096});
+		workers.run(pieces, planes, dst->exit_coord_weights, rec, ne);
 	};
 	size_t prev_done = 0, prev_n = 0;
-	int c = 0;
+	int c = 0, part = 0;
 	for (size_t done = 0; done < (size_t)count; done += chunk, c++) {
 		const size_t n = ((size_t)count - done < chunk) ? (size_t)count - done : chunk;
 		const int b = c & 1;
-		double *d_buf = ctx->d_stage + (size_t)b*chunk*rec, *h_buf = ctx->h_stage + (size_t)b*chunk*rec;
-		hipLaunchKernelGGL(pc_images_transpose_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, ctx->stream,
-		                   ctx->d_img, (long long)rec, (long long)(first + (int64_t)done), (long long)n, (int)ne, d_buf);
-		PC_HIP_CHECK(hipGetLastError());
-		PC_HIP_CHECK(hipMemcpyAsync(h_buf, d_buf, n*rec*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-		PC_HIP_CHECK(hipEventRecord(ctx->ev_fetch[b], ctx->stream));
+		double *h_buf = ctx->h_stage + (size_t)b*chunk*rec;
+		if (ctx->n_parts > 1) {
+			/* the last slot of the chunk decides which part has to be finished */
+			const long long last = first + (long long)(done + n) - 1;
+			while (part < ctx->n_parts - 1 && ctx->part_end[part] <= last) part++;
+			PC_HIP_CHECK(hipStreamWaitEvent(ctx->fetch_stream, ctx->ev_part[part], 0));
+		}
+		PC_HIP_CHECK(hipMemcpyAsync(h_buf, ctx->d_img + ((size_t)first + done)*rec, n*rec*sizeof(double), hipMemcpyDeviceToHost,
+		                            ctx->n_parts > 1 ? ctx->fetch_stream : ctx->stream));
+		PC_HIP_CHECK(hipEventRecord(ctx->ev_fetch[b], ctx->n_parts > 1 ? ctx->fetch_stream : ctx->stream));
 		if (c > 0) {
 			PC_HIP_CHECK(hipEventSynchronize(ctx->ev_fetch[b ^ 1]));
 			scatter(ctx->h_stage + (size_t)(b ^ 1)*chunk*rec, prev_done, prev_n);

@@ -253,7 +253,7 @@ pc_trace_pool_kernel(pc_kargs a)
 					if (chunk_end - chunk_next < k) {
 						long long have = chunk_end - chunk_next;
 						long long base_new = 0;
-						if (lane == 0) base_new = (long long)atomicAdd(&a.totals->next_slot, (unsigned long long)PC_CHUNK);
+						if (lane == 0) base_new = (long long)atomicAdd(a.work, (unsigned long long)PC_CHUNK);
 						base_new = __shfl(base_new, 0, PC_WAVE);
 						if (L.state == LS_NEED_SLOT)
 							L.slot = (rank < have) ? (chunk_next + rank) : (base_new + (rank - have));

@@ -390,25 +390,28 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 	uint32_t max_attempts = (uint32_t)pc_env_u64("POLYCAP_MAX_ATTEMPTS", 1u << 20, NULL);
 
 	int64_t counters[6] = {0, 0, 0, 0, 0, 0};
-	int status = leak_calc ? pc_hip_transmission_run_leak(ctx, seed, 0, n_photons, max_attempts, 1)
-	                       : pc_hip_transmission_run(ctx, seed, 0, n_photons, max_attempts, 1);
+	/* big plain runs are traced in four parts so that the images of a finished part cross PCIe while the next part runs */
+	int status = pc_hip_set_option(ctx, "run_parts", (!leak_calc && n_photons >= 2000000) ? (int)pc_env_u64("POLYCAP_RUN_PARTS", 4, NULL) : 1);
+	if (status == PC_HIP_OK)
+		status = leak_calc ? pc_hip_transmission_run_leak(ctx, seed, 0, n_photons, max_attempts, 1)
+		                   : pc_hip_transmission_run(ctx, seed, 0, n_photons, max_attempts, 1);
 	t_stage[2] = pc_now_ms();
+	t_stage[3] = t_stage[2];
 	if (status == PC_HIP_OK) {
 		pc_transeff_prefault(eff, (size_t)n_photons);    /* the kernel is running: fault the result pages in meanwhile */
 		t_stage[3] = pc_now_ms();
-		status = pc_hip_transmission_wait(ctx, NULL);
+		pc_hip_images dst;
+		pc_transeff_plane_pointers(eff, &dst);
+		status = pc_hip_transmission_images(ctx, 0, n_photons, &dst);    /* waits part by part (a leak run: for all of it) */
 	}
 	t_stage[4] = pc_now_ms();
 	if (status == PC_HIP_OK)
+		status = pc_hip_transmission_wait(ctx, NULL);
+	if (status == PC_HIP_OK)
 		status = pc_hip_transmission_totals(ctx, sum_weights, counters, NULL);
-	if (status == PC_HIP_OK) {
-		pc_hip_images dst;
-		pc_transeff_plane_pointers(eff, &dst);
-		status = pc_hip_transmission_images(ctx, 0, n_photons, &dst);
-	}
 	t_stage[5] = pc_now_ms();
 	if (timing)
-		fprintf(stderr, "polycap timing [ms]: alloc+context %.1f, enqueue %.1f, prefault %.1f, wait %.1f, totals+images %.1f\n",
+		fprintf(stderr, "polycap timing [ms]: alloc+context %.1f, enqueue %.1f, prefault %.1f, images (incl. waiting for the kernel) %.1f, totals %.1f\n",
 			t_stage[1] - t_stage[0], t_stage[2] - t_stage[1], t_stage[3] - t_stage[2], t_stage[4] - t_stage[3], t_stage[5] - t_stage[4]);
 	if (status == PC_HIP_OK && leak_calc)
 		status = pc_transeff_fetch_leaks(eff, ctx);      /* reference :925-1032 */

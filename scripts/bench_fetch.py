@@ -19,6 +19,10 @@ with polycap_amd.TraceContext(prob) as ctx:
         t0 = time.perf_counter(); ctx.run(2, 0, n, keep_images=True); ms = ctx.wait(); t1 = time.perf_counter()
         r = ctx.images(0, n); t2 = time.perf_counter()
         print("rep %d: run+wait %.1f ms (kernel %.1f ms), images() %.1f ms = %.2f GB/s" % (rep, (t1 - t0)*1e3, ms, (t2 - t1)*1e3, 18*8*n/(t2 - t1)/1e9), flush=True)
+    for parts in (1, 2, 4, 8, 16):
+        ctx.set_option("run_parts", parts)
+        ctx.run(2, 0, n, keep_images=True); ms = ctx.wait()
+        print("run_parts=%d: kernel(s) %.2f ms" % (parts, ms), flush=True)
 src0 = capi.Source.new_from_file(inp)
 desc = capi.Description(None, 0, 0, None, 0, _handle=capi._lib().polycap_source_get_description(src0._h), _owner=src0)
 src = capi.Source(desc, 2000., 0.2065, 0.2065, 0., 0., 0., 0., 0., np.array([10.0]))

@@ -183,6 +183,14 @@ def test_partition_invariance_and_reproducibility(pa, oracle):
         ctx.set_option("blocks_per_cu", 2)
         b0 = ctx.transmission(99, 0, 20000, keep_images=True)
         b1 = ctx.transmission(99, 20000, n - 20000, keep_images=True)
+        # one run traced as several launches on two streams (what the public API does to overlap the image fetch)
+        big = 400000
+        c1 = ctx.transmission(7, 5, big, keep_images=True)
+        ctx.set_option("run_parts", 5)
+        c5 = ctx.transmission(7, 5, big, keep_images=True)
+        ctx.set_option("run_parts", 1)
+    assert np.array_equal(c1["counters"][:4], c5["counters"][:4]) and np.array_equal(c1["sumw_fixed"], c5["sumw_fixed"])
+    assert np.array_equal(c1["images"], c5["images"], equal_nan=True) and np.array_equal(c1["exit_weights"], c5["exit_weights"])
     assert np.array_equal(a["counters"][:4], a2["counters"][:4]) and np.array_equal(a["sumw_fixed"], a2["sumw_fixed"])
     assert np.array_equal(a["counters"][:4], b0["counters"][:4] + b1["counters"][:4])
     assert np.array_equal(a["images"], np.vstack([b0["images"], b1["images"]]), equal_nan=True)
