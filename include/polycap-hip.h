@@ -72,10 +72,18 @@ POLYCAP_EXTERN const char *pc_hip_last_error(void);
 POLYCAP_EXTERN int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ctx);
 POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
 
-/* Tuning / test switches: "literal_march" (1 = visit every segment with the reference's full quadratic,
- * 0 = certified skipping, default), "event_threshold" (lanes), "blocks_per_cu", "block_size"; for leak runs
- * "leak_max_depth" (stack frames per lane = walls one photon may cross), "leak_stack_mb" (HBM for those stacks),
- * "leak_capacity" (leak record buffer, 0 = automatic; a run that outgrows it is repeated with a larger one). */
+/* Tuning / test switches (none of them changes a result):
+ *   "literal_march"    1 = visit every segment with the reference's full quadratic, 0 = certified skipping (default)
+ *   "event_threshold", "new_threshold", "march_burst", "blocks_per_cu", "block_size"   scheduler / launch shape
+ *   "lds_ec"           many energies: per-energy constants staged in LDS (default 1)
+ *   "pool", "pool_refill", "pool_march_min", "pool_event_min", "pool_new_min"   single-energy runs: the opt-in kernel
+ *                      that parks 64 more photons per wave in LDS (pc_pool_kernel.h); default off
+ *   "run_parts"        a transmission run that keeps images is traced as this many consecutive launches on two streams,
+ *                      so that pc_hip_transmission_images can fetch finished parts while later ones run (default 1;
+ *                      polycap_source_get_transmission_efficiencies uses 4 from 2e6 photons on)
+ *   "fetch_threads"    host threads that turn fetched image records into the caller's planes (0 = min(16, cores))
+ *   leak runs: "leak_max_depth" (stack frames per lane = walls one photon may cross), "leak_stack_mb" (HBM for those
+ *                      stacks), "leak_capacity" (leak record buffer, 0 = automatic; a run that outgrows it is repeated). */
 POLYCAP_EXTERN int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value);
 
 /* polycap_photon_launch (src/polycap-photon.c:390-955, leak_calc=false) for n explicit photons.
@@ -103,7 +111,9 @@ POLYCAP_EXTERN int pc_hip_transmission_wait(pc_hip_ctx *ctx, float *kernel_ms);
  * sum_irefl, failed_slots, launches}; sumw_fixed (optional) [2*n_energies] = exact 128-bit fixed-point sums
  * (lo, hi) in units of 2^-62, which add exactly across devices. */
 POLYCAP_EXTERN int pc_hip_transmission_totals(pc_hip_ctx *ctx, double *sum_weights, int64_t counters[6], uint64_t *sumw_fixed);
-/* Copies image planes of slots [first, first+count) (relative to slot0 of the last run) to the host. */
+/* Copies image planes of slots [first, first+count) (relative to slot0 of the last run) to the host.  May be called
+ * before pc_hip_transmission_wait: with "run_parts" > 1 it waits for the run part by part and copies the finished parts
+ * while the later ones are traced (pinned staging, host threads build the planes).  NULL planes are skipped. */
 POLYCAP_EXTERN int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const pc_hip_images *dst);
 
 /* ---- leak_calc = true ("halo" photons): src/polycap-capil.c:610-619, 657-1194, src/polycap-photon.c:171-362, 645-907,
