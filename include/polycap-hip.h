@@ -115,6 +115,11 @@ POLYCAP_EXTERN int pc_hip_transmission_totals(pc_hip_ctx *ctx, double *sum_weigh
  * before pc_hip_transmission_wait: with "run_parts" > 1 it waits for the run part by part and copies the finished parts
  * while the later ones are traced (pinned staging, host threads build the planes).  NULL planes are skipped. */
 POLYCAP_EXTERN int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const pc_hip_images *dst);
+/* The same data as the device keeps it: one record of PC_HIP_N_PLANES + n_energies doubles per slot, the planes of
+ * pc_hip_images in their order (the reflection count as int64 bits in its place), then the slot's weights.
+ * records: [count][PC_HIP_N_PLANES + n_energies]. */
+#define PC_HIP_N_PLANES 17
+POLYCAP_EXTERN int pc_hip_transmission_records(pc_hip_ctx *ctx, int64_t first, int64_t count, double *records);
 
 /* ---- leak_calc = true ("halo" photons): src/polycap-capil.c:610-619, 657-1194, src/polycap-photon.c:171-362, 645-907,
  * src/polycap-source.c:799-879, 925-1032.  Same calls with the fraction of every reflection that is transmitted through

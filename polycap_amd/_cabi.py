@@ -138,6 +138,8 @@ def lib():
     L.pc_hip_transmission_totals.restype = C.c_int
     L.pc_hip_transmission_images.argtypes = [C.c_void_p, C.c_int64, C.c_int64, P(ImagesS)]
     L.pc_hip_transmission_images.restype = C.c_int
+    L.pc_hip_transmission_records.argtypes = [C.c_void_p, C.c_int64, C.c_int64, P(C.c_double)]
+    L.pc_hip_transmission_records.restype = C.c_int
     L.pc_hip_phase_stats.argtypes = [C.c_void_p, c_int64_p]
     L.pc_hip_phase_stats.restype = C.c_int
     L.pc_hip_efficiencies.argtypes = [C.c_size_t, c_double_p, c_int64_p, c_double_p]

@@ -601,11 +601,11 @@ public:
 		for (auto &t : threads_) t.join();
 	}
 	/* scatters every piece; returns when all are done (the calling thread works too) */
-	void run(const std::vector<pc_copy_piece> &pieces, void *const *planes, double *weights, size_t rec, size_t ne)
+	void run(const std::vector<pc_copy_piece> &pieces, void *const *planes, double *weights, size_t rec, size_t ne, double *raw = nullptr)
 	{
 		{
 			std::lock_guard<std::mutex> g(m_);
-			pieces_ = &pieces; planes_ = planes; weights_ = weights; rec_ = rec; ne_ = ne;
+			pieces_ = &pieces; planes_ = planes; weights_ = weights; rec_ = rec; ne_ = ne; raw_ = raw;
 			next_.store(0); busy_ = (int)threads_.size(); gen_++;
 		}
 		cv_work_.notify_all();
@@ -622,6 +622,7 @@ private:
 		const size_t nplanes = rec - ne;
 		for (size_t j = next_.fetch_add(1); j < pieces.size(); j = next_.fetch_add(1)) {
 			const pc_copy_piece &p = pieces[j];
+			if (raw_) { memcpy(raw_ + p.slot*rec, p.from, p.n*rec*sizeof(double)); continue; }     /* records as they are */
 			/* plane by plane: strided reads of a piece that fits the cache, contiguous writes (8-byte words: the
 			 * reflection count is an int64 plane) */
 			for (size_t k = 0; k < nplanes; k++) {
@@ -664,7 +665,7 @@ private:
 	std::condition_variable cv_work_, cv_done_;
 	const std::vector<pc_copy_piece> *pieces_ = nullptr;
 	void *const *planes_ = nullptr;
-	double *weights_ = nullptr;
+	double *weights_ = nullptr, *raw_ = nullptr;
 	size_t rec_ = 0, ne_ = 0;
 	std::atomic<size_t> next_{0};
 	unsigned long gen_ = 0;
@@ -714,6 +715,7 @@ struct pc_hip_ctx {
 	double *d_img = nullptr;               /* image records: n_slots x (17 + n_energies) doubles */
 	double *h_stage = nullptr;             /* image fetches: two pinned chunks of records on the host */
 	size_t h_stage_elems = 0;
+	bool h_stage_pinned = false;           /* false: pinning was refused (locked-memory limit), plain memory is used instead */
 	hipEvent_t ev_fetch[2] = {nullptr, nullptr};
 	hipStream_t fetch_stream = nullptr;    /* copies of finished parts run beside the kernel of the next part */
 	hipStream_t stream2 = nullptr;         /* odd parts: a part's first workgroups start as the previous part's last ones leave */
@@ -890,7 +892,7 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->d_ftables) (void)hipFree(ctx->d_ftables);
 	if (ctx->d_totals) (void)hipFree(ctx->d_totals);
 	if (ctx->d_img) (void)hipFree(ctx->d_img);
-	if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+	if (ctx->h_stage) { if (ctx->h_stage_pinned) (void)hipHostFree(ctx->h_stage); else free(ctx->h_stage); }
 	for (int k = 0; k < 2; k++) if (ctx->ev_fetch[k]) (void)hipEventDestroy(ctx->ev_fetch[k]);
 	for (int k = 0; k < PC_MAX_PARTS; k++) if (ctx->ev_part[k]) (void)hipEventDestroy(ctx->ev_part[k]);
 	if (ctx->fetch_stream) (void)hipStreamDestroy(ctx->fetch_stream);
@@ -1323,9 +1325,8 @@ int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6])
 	return PC_HIP_OK;
 }
 
-int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const pc_hip_images *dst)
+static int pc_fetch_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const pc_hip_images *dst, double *raw)
 {
-	if (!ctx || !dst) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: NULL argument");
 	if (!ctx->img_valid) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: the last run kept no images");
 	if (first < 0 || count < 0 || first + count > ctx->run_slots) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: slot range out of bounds");
 	/* a leak run is complete (and possibly repeated) only after wait(); a plain run is fetched part by part below */
@@ -1336,12 +1337,16 @@ int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, co
 	if (count == 0) return PC_HIP_OK;
 	PC_HIP_CHECK(hipSetDevice(ctx->device));
 	const size_t ne = (size_t)ctx->host.pm.n_energies, rec = (size_t)PC_N_PLANES + ne;
-	void *planes[PC_N_PLANES] = {
-		dst->src_start_coords[0], dst->src_start_coords[1], dst->pc_start_coords[0], dst->pc_start_coords[1],
-		dst->pc_start_dir[0], dst->pc_start_dir[1], dst->pc_start_elecv[0], dst->pc_start_elecv[1],
-		dst->pc_exit_coords[0], dst->pc_exit_coords[1], dst->pc_exit_coords[2],
-		dst->pc_exit_dir[0], dst->pc_exit_dir[1], dst->pc_exit_elecv[0], dst->pc_exit_elecv[1],
-		dst->pc_exit_nrefl, dst->pc_exit_dtravel };
+	void *planes[PC_N_PLANES] = {nullptr};
+	if (dst) {
+		void *p[PC_N_PLANES] = {
+			dst->src_start_coords[0], dst->src_start_coords[1], dst->pc_start_coords[0], dst->pc_start_coords[1],
+			dst->pc_start_dir[0], dst->pc_start_dir[1], dst->pc_start_elecv[0], dst->pc_start_elecv[1],
+			dst->pc_exit_coords[0], dst->pc_exit_coords[1], dst->pc_exit_coords[2],
+			dst->pc_exit_dir[0], dst->pc_exit_dir[1], dst->pc_exit_elecv[0], dst->pc_exit_elecv[1],
+			dst->pc_exit_nrefl, dst->pc_exit_dtravel };
+		memcpy(planes, p, sizeof(p));
+	}
 	/* Pipeline over chunks of <= 16 MB of records: one asynchronous copy (DMA engine, no compute units) of the chunk into
 	 * pinned host memory, then host threads turn the records of the previous chunk into the caller's SoA planes while the
 	 * next one is in flight.  The copies run on their own stream and wait only for the part of the run that holds the
@@ -1350,10 +1355,17 @@ int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, co
 	if (chunk < 256) chunk = 256;
 	if (chunk > (size_t)count) chunk = (size_t)count;
 	if (ctx->h_stage_elems < 2*chunk*rec) {
-		if (ctx->h_stage) PC_HIP_CHECK(hipHostFree(ctx->h_stage));
+		if (ctx->h_stage) { if (ctx->h_stage_pinned) PC_HIP_CHECK(hipHostFree(ctx->h_stage)); else free(ctx->h_stage); }
 		ctx->h_stage = nullptr; ctx->h_stage_elems = 0;
-		if (hipHostMalloc(&ctx->h_stage, 2*chunk*rec*sizeof(double), hipHostMallocDefault) != hipSuccess)
-			return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_images: could not allocate the pinned staging buffer");
+		ctx->h_stage_pinned = true;
+		if (hipHostMalloc(&ctx->h_stage, 2*chunk*rec*sizeof(double), hipHostMallocDefault) != hipSuccess) {
+			/* no pinned memory to be had: the copies then go through the runtime's own staging, slower but correct */
+			(void)hipGetLastError();
+			ctx->h_stage_pinned = false;
+			ctx->h_stage = (double *)malloc(2*chunk*rec*sizeof(double));
+			if (!ctx->h_stage)
+				return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_images: could not allocate the staging buffer");
+		}
 		ctx->h_stage_elems = 2*chunk*rec;
 	}
 	for (int k = 0; k < 2; k++)
@@ -1372,7 +1384,7 @@ int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, co
 		pieces.clear();
 		for (size_t o = 0; o < n; o += 4096)
 			pieces.push_back({src + o*rec, done + o, n - o < 4096 ? n - o : 4096});
-		workers.run(pieces, planes, dst->exit_coord_weights, rec, ne);
+		workers.run(pieces, planes, dst ? dst->exit_coord_weights : nullptr, rec, ne, raw);
 	};
 	size_t prev_done = 0, prev_n = 0;
 	int c = 0, part = 0;
@@ -1398,6 +1410,18 @@ int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, co
 	PC_HIP_CHECK(hipEventSynchronize(ctx->ev_fetch[(c - 1) & 1]));
 	scatter(ctx->h_stage + (size_t)((c - 1) & 1)*chunk*rec, prev_done, prev_n);
 	return PC_HIP_OK;
+}
+
+int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const pc_hip_images *dst)
+{
+	if (!ctx || !dst) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: NULL argument");
+	return pc_fetch_images(ctx, first, count, dst, nullptr);
+}
+
+int pc_hip_transmission_records(pc_hip_ctx *ctx, int64_t first, int64_t count, double *records)
+{
+	if (!ctx || !records) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_records: NULL argument");
+	return pc_fetch_images(ctx, first, count, nullptr, records);
 }
 
 /* src/polycap-source.c:1066-1076 */

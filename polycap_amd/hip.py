@@ -154,6 +154,22 @@ class TraceContext:
                         avg_lanes=float(st[2 * i + 1]) / max(1, int(st[2 * i]))) for i, n in enumerate(names)}
 
     def images(self, first=0, count=None):
+        """Image data of slots [first, first+count) of the last run: images [count, 17] (the planes of pc_hip_images in
+        their order, one row per slot, the reflection count as a float in column 15), exit_weights [count, nE], nrefl.
+        One row per slot is also how the device keeps them, so the records are fetched as they are."""
+        count = self._last_n - first if count is None else count
+        ne = self.problem.n_energies
+        rec = np.empty((count, 17 + ne))
+        st = self._L.pc_hip_transmission_records(self._h, int(first), int(count), dptr(rec))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_transmission_records", st)
+        nrefl = rec[:, 15].view(np.int64).copy() if count else np.zeros(0, dtype=np.int64)
+        rec[:, 15] = nrefl
+        return dict(images=rec[:, :17], exit_weights=rec[:, 17:], nrefl=nrefl)
+
+    def image_planes(self, first=0, count=None):
+        """The same through pc_hip_transmission_images: SoA planes [17, count] as the reference's struct _polycap_images
+        holds them (what the C host layer uses), exit_weights [count, nE], nrefl."""
         count = self._last_n - first if count is None else count
         ne = self.problem.n_energies
         planes = np.zeros((17, count))
@@ -164,7 +180,7 @@ class TraceContext:
         if st != _cabi.PC_HIP_OK:
             raise HipError("pc_hip_transmission_images", st)
         planes[15] = nrefl
-        return dict(images=planes.T.copy(), exit_weights=w, nrefl=nrefl)
+        return dict(planes=planes, exit_weights=w, nrefl=nrefl)
 
     def transmission(self, seed, slot0, n_slots, max_attempts=1 << 20, keep_images=False, leak_calc=False):
         """run + wait + totals (+ images, + leak events) in one call."""

@@ -188,7 +188,10 @@ def test_partition_invariance_and_reproducibility(pa, oracle):
         c1 = ctx.transmission(7, 5, big, keep_images=True)
         ctx.set_option("run_parts", 5)
         c5 = ctx.transmission(7, 5, big, keep_images=True)
+        planes = ctx.image_planes(1000, big - 3000)      # the SoA fetch of the C host layer against the record fetch
         ctx.set_option("run_parts", 1)
+    assert np.array_equal(planes["planes"].T, c5["images"][1000:big - 2000], equal_nan=True)
+    assert np.array_equal(planes["exit_weights"], c5["exit_weights"][1000:big - 2000])
     assert np.array_equal(c1["counters"][:4], c5["counters"][:4]) and np.array_equal(c1["sumw_fixed"], c5["sumw_fixed"])
     assert np.array_equal(c1["images"], c5["images"], equal_nan=True) and np.array_equal(c1["exit_weights"], c5["exit_weights"])
     assert np.array_equal(a["counters"][:4], a2["counters"][:4]) and np.array_equal(a["sumw_fixed"], a2["sumw_fixed"])
