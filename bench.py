@@ -43,6 +43,26 @@ def measured_traffic(n_local, keep_images):
         return (s["FETCH_SIZE"] + s["WRITE_SIZE"]) * 1024.0
     except Exception:
         return None
+
+
+def valu_issue(n_local, keep_images, kernel_ms):
+    """VALU issue rate of the trace kernel: wave-instructions per launch from the committed PMC summary (SQ_INSTS_VALU, same
+    workload only) over the live kernel time, against 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz.
+    This, not HBM, is the resource the kernel saturates; what is left is the lane utilisation of those instructions."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            s = json.load(f)
+        if n_local != 10_000_000 or not keep_images:
+            return None
+        peak = 256 * 4 * 2.4e9 / 4.0
+        rate = s["SQ_INSTS_VALU"] / (kernel_ms * 1e-3)
+        return {"wave_instructions_per_launch": s["SQ_INSTS_VALU"], "achieved_per_s": rate, "peak_per_s": peak, "frac": rate / peak,
+                "lane_utilisation": s["SQ_THREAD_CYCLES_VALU"] / (64.0 * s["SQ_ACTIVE_INST_VALU"]),
+                "source": "profiles/r01/v8_pmc_summary.json (rocprofv3 --pmc) / HIP-event kernel time of this run"}
+    except Exception:
+        return None
+
+
 BYTES_PER_EXIT_PHOTON = 17 * 8   # 17 image planes of 8 B; + 8 B per energy for exit_coord_weights
 
 
@@ -178,7 +198,7 @@ def main():
                          "kernel": "pc_trace_kernel<1,0>", "kernel_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "fp64-VALU/divergence-bound by construction (SURVEY 8d): 144 B per exit photon",
-                         "valu_fp64": valu},
+                         "valu_fp64": valu, "valu_issue": valu_issue(n_local, keep_images, avg_ms)},
         }
         if keep_images and world == 1:
             # not part of `value`: the same workload through the public C API (polycap_source_get_transmission_efficiencies),
