@@ -203,8 +203,7 @@ void pc_transeff_prefault(polycap_transmission_efficiencies *eff, size_t np)
 	for (int t = 0; t < nt; t++) {
 		args[t].jobs = jobs; args[t].njobs = nj; args[t].tid = t; args[t].nthreads = nt;
 		if (t > 0 && pthread_create(&th[t], NULL, pc_touch_thread, &args[t]) != 0) {
-			/* no thread: this slice is touched by the caller below */
-			th[t] = 0;
+			/* no thread: the caller touches this slice itself */
 			pc_touch_thread(&args[t]);
 			continue;
 		}

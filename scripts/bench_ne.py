@@ -26,4 +26,5 @@ with polycap_amd.TraceContext(prob) as ctx:
     st = ctx.phase_stats()
 print("%s n_E=%d sig=%s %s: %d exit slots, %d started, kernel %.2f ms, %.4g started photons/s (wall %.3f s), eff[0]=%.4f eff[-1]=%.4f"
       % (deck, ne, sig, opts, n, r["i_start"], r["kernel_ms"], r["i_start"] / (r["kernel_ms"] * 1e-3), dt, r["efficiencies"][0], r["efficiencies"][-1]))
-print("  avg lanes: march %.1f event %.1f new %.1f" % (st["march"]["avg_lanes"], st["event"]["avg_lanes"], st["new"]["avg_lanes"]))
+print("  avg lanes: march %.1f event %.1f new %.1f; wave-level phases: march steps %.3g, event %.3g, new %.3g"
+      % (st["march"]["avg_lanes"], st["event"]["avg_lanes"], st["new"]["avg_lanes"], st["march"]["phases"], st["event"]["phases"], st["new"]["phases"]))
