@@ -75,6 +75,10 @@ def main():
     ap.add_argument("--seed", type=int, default=20000)
     ap.add_argument("--no-images", action="store_true", help="histogram-only mode (no per-photon planes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pcie", action="store_true",
+                    help="also time one polycap_source_get_transmission_efficiencies call of the same size through the public C API "
+                         "(results in host arrays: the PCIe-inclusive rate of DESIGN.md; off by default so that the command launches "
+                         "nothing but the timed kernel)")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="exit-photon slots of the CPU baseline sample (0 = sized from a short probe to about 15 s of CPU work)")
     ap.add_argument("--opt", action="append", default=[], help="kernel option name=value (event_threshold, blocks_per_cu, ...)")
@@ -200,7 +204,7 @@ def main():
                          "note": "fp64-VALU/divergence-bound by construction (SURVEY 8d): 144 B per exit photon",
                          "valu_fp64": valu, "valu_issue": valu_issue(n_local, keep_images, avg_ms)},
         }
-        if keep_images and world == 1:
+        if args.pcie and keep_images and world == 1:
             # not part of `value`: the same workload through the public C API (polycap_source_get_transmission_efficiencies),
             # i.e. kernel + all 18 image planes copied into host arrays over PCIe
             out["pcie_inclusive_photons_per_s"] = pcie_inclusive(deck, n_local, started / float(args.steps * n_local))
