@@ -467,3 +467,23 @@ def test_photon_pool_kernel_is_bit_identical(pa, oracle):
             if max_attempts == 2:
                 assert a["failed_slots"] > 0 and not done.all()
             assert swaps["march"]["phases"] > 0
+
+
+def test_image_fetch_paths_agree_on_a_multi_energy_run(pa, oracle):
+    """Records (pc_hip_transmission_records) and SoA planes (pc_hip_transmission_images, fetched before wait() from a run
+    cut into parts) carry the same data, weights of 7 energies included; sizes above the threaded-pipeline threshold."""
+    optic, src, prob, _ = make_pair(oracle, "ellip", energies=(5.0, 8.0, 11.0, 14.0, 17.0, 20.0, 25.0))
+    n = 200000
+    with pa.TraceContext(prob) as ctx:
+        a = ctx.transmission(3, 11, n, keep_images=True)
+        ctx.set_option("run_parts", 3)
+        ctx.set_option("fetch_threads", 5)
+        ctx.run(3, 11, n, keep_images=True)
+        p = ctx.image_planes(0, n)
+        ctx.wait()
+        b = ctx.totals()
+        r = ctx.images(100, n - 300)
+    assert np.array_equal(a["images"], p["planes"].T, equal_nan=True) and np.array_equal(a["exit_weights"], p["exit_weights"])
+    assert np.array_equal(a["images"][100:n - 200], r["images"], equal_nan=True)
+    assert np.array_equal(a["exit_weights"][100:n - 200], r["exit_weights"])
+    assert np.array_equal(a["counters"][:4], b["counters"][:4]) and np.array_equal(a["sumw_fixed"], b["sumw_fixed"])
