@@ -36,7 +36,7 @@
 #define PC_WAVE 64
 #define PC_MAX_PITCH 2048      /* largest profile kept in static LDS: (6 x 8 + 4 x 4) B x 2048 = 128 KB */
 #ifndef PC_MARCH_UNROLL
-#define PC_MARCH_UNROLL 4      /* march steps between two ballots of the burst loop */
+#define PC_MARCH_UNROLL 8      /* march steps between two ballots of the burst loop (4: 32.5 ms, 8: 31.9 ms, 12: 33.1 ms; scripts/ab_flags.sh) */
 #endif
 #define PC_KE 5                /* energies per lane whose weights are in flight together in a cooperative sweep */
 #ifndef PC_CHUNK
