@@ -28,7 +28,7 @@ import numpy as np
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this same command, condensed by scripts/summarize_profile.py
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "v10_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "v11_pmc_summary.json")
 
 
 def measured_traffic(n_local, keep_images):
@@ -58,7 +58,7 @@ def valu_issue(n_local, keep_images, kernel_ms):
         rate = s["SQ_INSTS_VALU"] / (kernel_ms * 1e-3)
         return {"wave_instructions_per_launch": s["SQ_INSTS_VALU"], "achieved_per_s": rate, "peak_per_s": peak, "frac": rate / peak,
                 "lane_utilisation": s["SQ_THREAD_CYCLES_VALU"] / (64.0 * s["SQ_ACTIVE_INST_VALU"]),
-                "source": "profiles/r01/v10_pmc_summary.json (rocprofv3 --pmc) / HIP-event kernel time of this run"}
+                "source": "profiles/r01/v11_pmc_summary.json (rocprofv3 --pmc) / HIP-event kernel time of this run"}
     except Exception:
         return None
 

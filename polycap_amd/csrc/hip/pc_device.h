@@ -76,8 +76,16 @@ struct pc_tables {
 	const float *mb1, *md1, *mb2, *md2;
 };
 
-#define PC_L1 8     /* strides of the two block-certificate levels, in segments */
-#define PC_L2 32
+#ifndef PC_L1
+#define PC_L1 5     /* strides of the two block-certificate levels, in segments (flights between two reflections span 23
+                     * segments on average, half of them fewer than 8: scripts/analysis/flight_stats.py, scripts/ab_strides.sh) */
+#endif
+#ifndef PC_L2
+#define PC_L2 25
+#endif
+#ifndef PC_LV_LATER
+#define PC_LV_LATER 2  /* widest level a flight after a reflection starts with */
+#endif
 
 template <int NE>
 struct pc_photon {
@@ -312,7 +320,7 @@ PC_HD void pc_trace_begin(pc_photon<NE> &ph)
 	pc_ray_setup(ph);
 	ph.first = 1;
 	/* long first flight: start with the widest stride; after a reflection flights are short */
-	ph.lv = ph.bnd ? 0 : ((ph.irefl == 0) ? 2 : 1);
+	ph.lv = ph.bnd ? 0 : ((ph.irefl == 0) ? 2 : PC_LV_LATER);
 }
 
 /* src/polycap-photon.c:458-645 + 888-906.  Returns PC_ST_MARCH when the photon entered a capillary,

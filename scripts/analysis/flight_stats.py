@@ -24,7 +24,10 @@ ph = pyemul.sample(prob, 11, np.arange(n), np.zeros(n, dtype=np.uint32))
 start, direc, elecv = (np.ascontiguousarray(ph[:, a:a + 3]) for a in (0, 3, 6))
 dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
 ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
-configs = [((8, 32), 2, 1, 0), ((8, 32), 2, 2, 0), ((4, 16, 64, 256), 4, 3, 0), ((8, 32), 2, 2, 4), ((8, 32), 2, 1, 4), ((8, 32), 2, 2, 8), ((8, 32), 2, 1, 8), ((16, 64), 2, 2, 4), ((16, 64), 2, 2, 8), ((8, 32, 128), 3, 2, 4), ((4, 16, 64), 3, 3, 4), ((4, 16, 64), 3, 3, 2), ((8, 32), 2, 2, 2)]
+configs = [((8, 32), 2, 1, 0), ((8, 32), 2, 2, 0), ((4, 16), 2, 2, 0), ((6, 24), 2, 2, 0), ((6, 36), 2, 2, 0), ((5, 25), 2, 2, 0), ((8, 64), 2, 2, 0),
+           ((12, 48), 2, 2, 0), ((4, 32), 2, 2, 0), ((4, 24), 2, 2, 0), ((3, 18), 2, 2, 0), ((5, 40), 2, 2, 0), ((6, 48), 2, 2, 0), ((4, 16, 64), 3, 3, 0), ((3, 12, 48), 3, 3, 0)]
+if len(sys.argv) > 3:
+    configs = [c for c in configs if c[3] == 0]
 for strides, lf, ll, npr in configs:
     out = np.zeros(4, dtype=np.int64)
     hf, hl = np.zeros(64, dtype=np.int64), np.zeros(64, dtype=np.int64)
