@@ -12,11 +12,9 @@ while IFS= read -r flags; do
   fi
 done <<'FLAGS'
 
--DPC_LV_LATER=2
--DPC_L1=4 -DPC_L2=16 -DPC_LV_LATER=2
--DPC_L1=4 -DPC_L2=16 -DPC_LV_LATER=1
--DPC_L1=4 -DPC_L2=24 -DPC_LV_LATER=2
--DPC_L1=5 -DPC_L2=25 -DPC_LV_LATER=2
--DPC_L1=3 -DPC_L2=18 -DPC_LV_LATER=2
--DPC_L1=6 -DPC_L2=24 -DPC_LV_LATER=2
+-DPC_CHUNK=32
+-DPC_CHUNK=64
+-DPC_CHUNK=256
+
+-DPC_CHUNK=32
 FLAGS
