@@ -28,7 +28,7 @@ import numpy as np
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this same command, condensed by scripts/summarize_profile.py
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "v11_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "v12_pmc_summary.json")
 
 
 def measured_traffic(n_local, keep_images):
@@ -58,7 +58,7 @@ def valu_issue(n_local, keep_images, kernel_ms):
         rate = s["SQ_INSTS_VALU"] / (kernel_ms * 1e-3)
         return {"wave_instructions_per_launch": s["SQ_INSTS_VALU"], "achieved_per_s": rate, "peak_per_s": peak, "frac": rate / peak,
                 "lane_utilisation": s["SQ_THREAD_CYCLES_VALU"] / (64.0 * s["SQ_ACTIVE_INST_VALU"]),
-                "source": "profiles/r01/v11_pmc_summary.json (rocprofv3 --pmc) / HIP-event kernel time of this run"}
+                "source": "profiles/r01/v12_pmc_summary.json (rocprofv3 --pmc) / HIP-event kernel time of this run"}
     except Exception:
         return None
 
@@ -199,7 +199,7 @@ def main():
             "scheduler": sched,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local, keep_images),
-                         "kernel": "pc_trace_kernel<1,0>", "kernel_ms": avg_ms,
+                         "kernel": "pc_trace_kernel<1,0>" if "pool=0" in args.opt else "pc_trace_pool_kernel<0>", "kernel_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "fp64-VALU/divergence-bound by construction (SURVEY 8d): 144 B per exit photon",
                          "valu_fp64": valu, "valu_issue": valu_issue(n_local, keep_images, avg_ms)},

@@ -703,7 +703,7 @@ struct pc_hip_ctx {
 	int march_burst = 16;
 	int blocks_per_cu = 2;
 	int block_size = 512;
-	int pool = 0;                  /* single-energy source runs: per-wave photon pool in LDS (pc_pool_kernel.h) */
+	int pool = 1;                  /* single-energy source runs on profiles of up to 1024 points: per-wave photon pool in LDS (pc_pool_kernel.h), +6 % */
 	int pool_refill = 20;
 	int pool_march_min = 16;
 	int pool_event_min = 48;

@@ -1,4 +1,5 @@
-/* Single-energy trace kernel with a per-wave photon pool in LDS (included by pc_kernels.hip).  Opt-in: option "pool".
+/* Single-energy trace kernel with a per-wave photon pool in LDS (included by pc_kernels.hip).  Option "pool", on by
+ * default; the one-photon-per-lane kernel pc_trace_kernel<1, MODE> serves what this one does not (pc_pool_applies).
  *
  * pc_trace_kernel keeps one photon per lane, so a MARCH phase runs with the lanes that happen to be in flight (about 20
  * of 64 on xos1: flights are a few steps long and every lane then waits for an EVENT phase).  Here every wave owns
@@ -15,7 +16,8 @@
  *   1024 threads/CU (128 VGPRs, 195 spilled), 48 parked: 55 ms;  512 threads/CU (212 VGPRs, no spills), 64 parked: 15.7 ms;
  *   768 threads/CU (168 VGPRs, 40 spilled), 64 parked: 14.3 ms  <- the build default.
  * The fuller phases are paid for with the registers of the exchange code and fewer resident waves (the lane kernel
- * itself is 1.6x slower at 12 waves per CU than at 16), so the net gain is 5 %: not the default path. */
+ * itself is 1.6x slower at 12 waves per CU than at 16), so the net gain was 5 % with the march of that time and is 6 %
+ * on the full benchmark (1e7 slots: 29.5 ms against 31.3 ms, scripts/ab_pool_default.sh) with the current one. */
 #ifndef PC_POOL_KERNEL_H
 #define PC_POOL_KERNEL_H
 

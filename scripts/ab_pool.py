@@ -23,6 +23,7 @@ def stats(ctx):
 with polycap_amd.TraceContext(prob) as ctx:
     # identity on a small run with images, then on the big one without
     m = min(n, 200000)
+    ctx.set_option("pool", 0)
     ref = ctx.transmission(7, 123, m, keep_images=True)
     ctx.set_option("pool", 1)
     for k, v in opts:

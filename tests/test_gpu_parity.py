@@ -441,14 +441,16 @@ def test_many_energies_match_the_host_compile(pa, oracle, n_energies):
 
 
 def test_photon_pool_kernel_is_bit_identical(pa, oracle):
-    """Option "pool": photons parked in LDS are exchanged between lanes (pc_pool_kernel.h).  A photon depends on
-    (seed, slot, attempt) only and the sums are exact, so totals and every image plane equal the lane kernel's."""
+    """Option "pool" (the default for single-energy source runs): photons parked in LDS are exchanged between lanes
+    (pc_pool_kernel.h).  A photon depends on (seed, slot, attempt) only and the sums are exact, so totals and every image
+    plane equal those of the one-photon-per-lane kernel ("pool" = 0)."""
     from tests.common import make_custom, MONO_CASE, SEVEN_CASE
     probs = [make_pair(oracle, "xos1")[2], make_pair(oracle, "xos1", source=(2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.0))[2],
              make_custom(oracle, **MONO_CASE)[2], make_custom(oracle, **SEVEN_CASE)[2]]
     for k, prob in enumerate(probs):
         for n, max_attempts in ((60000, 1 << 20), (37, 1 << 20), (3000, 2)):
             with pa.TraceContext(prob) as ctx:
+                ctx.set_option("pool", 0)
                 ctx.run(31 + k, 1000, n, max_attempts=max_attempts, keep_images=True)
                 ctx.wait()
                 a = ctx.totals(check=False)
