@@ -17,7 +17,7 @@
  *   768 threads/CU (168 VGPRs, 40 spilled), 64 parked: 14.3 ms  <- the build default.
  * The fuller phases are paid for with the registers of the exchange code and fewer resident waves (the lane kernel
  * itself is 1.6x slower at 12 waves per CU than at 16), so the net gain was 5 % with the march of that time and is 6 %
- * on the full benchmark (1e7 slots: 29.5 ms against 31.3 ms, scripts/ab_pool_default.sh) with the current one. */
+ * on the full benchmark (1e7 slots: 28.8 ms against 31.3 ms, scripts/ab_pool_default.sh) with the current one. */
 #ifndef PC_POOL_KERNEL_H
 #define PC_POOL_KERNEL_H
 
@@ -31,6 +31,10 @@
 #define PQ_PITCH 1024
 #ifndef PQ_P
 #define PQ_P 64            /* parked photons per wave (at most 64: one mask bit each) */
+#endif
+#ifndef PQ_UNROLL
+#define PQ_UNROLL 16        /* march steps between two top-ups of the wave (2: 32.0 ms, 4: 30.3, 8: 29.4, 12-24: 29.0, 32: 29.6:
+                             * topping up in mid-burst does not pay, the pool earns its keep in the EVENT and NEW phases) */
 #endif
 #define PQ_R 15            /* doubles per parked photon */
 
@@ -185,14 +189,14 @@ pc_trace_pool_kernel(pc_kargs a)
 			}
 		}
 		if (X == 0) {
-			/* ---------------- MARCH: PC_MARCH_UNROLL certified steps */
+			/* ---------------- MARCH: PQ_UNROLL certified steps */
 			if (L.state == LS_MARCH && ph.first)
 				L.state = pc_march_step(T, Pm, ph);
 #pragma unroll
-			for (int u = 0; u < PC_MARCH_UNROLL; u++)
+			for (int u = 0; u < PQ_UNROLL; u++)
 				if (L.state == LS_MARCH)
 					L.state = pc_march_step_hot(T, Pm, ph);
-			st_march += PC_MARCH_UNROLL; st_march_l += PC_MARCH_UNROLL*(unsigned)__popcll(__ballot(L.state == LS_MARCH));
+			st_march += PQ_UNROLL; st_march_l += PQ_UNROLL*(unsigned)__popcll(__ballot(L.state == LS_MARCH));
 		} else if (X == 1) {
 			/* ---------------- EVENT */
 			st_event += 1; st_event_l += (unsigned)__popcll(__ballot(L.state == LS_EVENT));

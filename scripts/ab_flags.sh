@@ -11,10 +11,9 @@ while IFS= read -r flags; do
     echo "[$flags] does not compile: $(tail -1 /tmp/kf_$i.err)"
   fi
 done <<'FLAGS'
-
--DPC_CHUNK=32
--DPC_CHUNK=64
--DPC_CHUNK=256
-
--DPC_CHUNK=32
+-DPQ_UNROLL=12
+-DPQ_UNROLL=16
+-DPQ_UNROLL=24
+-DPQ_UNROLL=32
+-DPQ_UNROLL=16 -DPQ_P=48
 FLAGS
