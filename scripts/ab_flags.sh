@@ -11,9 +11,11 @@ while IFS= read -r flags; do
     echo "[$flags] does not compile: $(tail -1 /tmp/kf_$i.err)"
   fi
 done <<'FLAGS'
--DPQ_UNROLL=12
--DPQ_UNROLL=16
--DPQ_UNROLL=24
--DPQ_UNROLL=32
--DPQ_UNROLL=16 -DPQ_P=48
+
+-DPC_L1=4 -DPC_L2=16
+-DPC_L1=6 -DPC_L2=24
+-DPC_L1=8 -DPC_L2=32
+-DPC_L1=4 -DPC_L2=24
+-DPC_L1=3 -DPC_L2=15
+-DPC_L1=5 -DPC_L2=35
 FLAGS
