@@ -140,6 +140,29 @@ POLYCAP_EXTERN int pc_hip_leak_counts(pc_hip_ctx *ctx, int64_t *n_ext, int64_t *
 /* events [first, first+count) of kind 0 (extleak) or 1 (intleak) into records[count * (PC_HIP_LEAK_HDR + n_energies)] */
 POLYCAP_EXTERN int pc_hip_leak_events(pc_hip_ctx *ctx, int kind, int64_t first, int64_t count, double *records);
 
+/* Waits until the context's device is idle (hipDeviceSynchronize): every stream, not only the context's own. */
+POLYCAP_EXTERN int pc_hip_device_synchronize(pc_hip_ctx *ctx);
+
+/* ---- several devices from one process: the OpenMP team of the reference (src/polycap-source.c:697-745) becomes a group of
+ * device contexts, one per entry of `devices` (an index may repeat: the contexts then share that GPU).  A run shards the
+ * exit-photon slots [0, n_slots) into contiguous ranges, one per member, enqueued from the calling thread; photons are
+ * keyed by (seed, global slot), so the result does not depend on the partition.  The totals of the members -- counters and
+ * the exact 128-bit fixed-point weight sums, split into 32-bit limbs -- are added by ONE all-reduce over RCCL
+ * (librccl bound at run time, ncclCommInitAll over the group's devices: the reference's omp critical sum, :973-980) when
+ * the devices are distinct and RCCL is present, else limb by limb on the host: the same bits either way. */
+typedef struct pc_hip_group pc_hip_group;
+POLYCAP_EXTERN int pc_hip_group_create(const pc_hip_problem *problem, int n_devices, const int *devices, pc_hip_group **group);
+POLYCAP_EXTERN void pc_hip_group_destroy(pc_hip_group *group);
+POLYCAP_EXTERN int pc_hip_group_size(const pc_hip_group *group);
+POLYCAP_EXTERN int pc_hip_group_set_option(pc_hip_group *group, const char *name, int64_t value);
+POLYCAP_EXTERN int pc_hip_group_run(pc_hip_group *group, uint64_t seed, int64_t n_slots, uint32_t max_attempts, int keep_images);
+/* image planes of all n_slots slots of the last run (one host thread per member copies its range into dst) */
+POLYCAP_EXTERN int pc_hip_group_images(pc_hip_group *group, const pc_hip_images *dst);
+/* totals as pc_hip_transmission_totals; *reduced_by (optional) = 1 when the sum was made by RCCL, 0 on the host;
+ * *kernel_ms (optional) = the longest member kernel.  reduce: -1 automatic, 0 host, 1 RCCL (fails when it cannot) */
+POLYCAP_EXTERN int pc_hip_group_totals(pc_hip_group *group, int reduce, double *sum_weights, int64_t counters[6], uint64_t *sumw_fixed,
+	int *reduced_by, float *kernel_ms);
+
 /* Scheduler statistics of the last transmission run (diagnostics): {march steps, march lane-steps, event phases,
  * event lanes, new phases, new lanes}, summed over all waves; lanes/phases = average active lanes per phase. */
 POLYCAP_EXTERN int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6]);

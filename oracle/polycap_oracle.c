@@ -458,6 +458,22 @@ int orc_trace(const orc_optic *optic, int *ix, orc_photon *photon, const double 
 
 /* ------------------------------------------------------------------ launch */
 
+/* per-thread pair of axis arrays (see orc_launch); grown on demand and kept for the life of the thread */
+static int orc_axis_scratch(int n, double **cap_x, double **cap_y)
+{
+	static __thread double *buf = NULL;
+	static __thread int have = 0;
+	if (have < n) {
+		double *nb = realloc(buf, sizeof(double) * 2 * (size_t)n);
+		if (nb == NULL) return -1;
+		buf = nb;
+		have = n;
+	}
+	*cap_x = buf;
+	*cap_y = buf + n;
+	return 0;
+}
+
 /* src/polycap-photon.c:390-955 (leak_calc = photon->leak_calc).
  * amu/scatf are supplied by the caller (the reference calls xraylib via polycap_photon_scatf
  * at :495 for every launch; the values depend only on composition and energy). */
@@ -530,9 +546,9 @@ int orc_launch(const orc_optic *optic, orc_photon *photon, size_t n_energies, co
 	}
 
 	/* :578-627 capillary axis */
-	cap_x = malloc(sizeof(double)*(nmax+1));
-	cap_y = malloc(sizeof(double)*(nmax+1));
-	if (cap_x == NULL || cap_y == NULL) { free(cap_x); free(cap_y); return -1; }
+	/* the reference mallocs and frees the two axis arrays in every launch (:578-581, :930-945); the oracle keeps one pair
+	 * per thread so that the OpenMP driver does not serialise on the allocator (same values, same fill loop) */
+	if (orc_axis_scratch(nmax + 1, &cap_x, &cap_y) != 0) return -1;
 	for (i = 0; i <= nmax; i++) {
 		zz = ext[i]/(2.*ORC_COSPI_6*(n_shells+1));
 		cap_y[i] = r_i * (3./2) * zz;
@@ -554,13 +570,9 @@ int orc_launch(const orc_optic *optic, orc_photon *photon, size_t n_energies, co
 		if (photon->leak_calc) {
 			/* :645-887 */
 			int rc = orc_launch_in_wall_leak(optic, photon, cap_x, cap_y, ix);
-			free(cap_x);
-			free(cap_y);
 			return rc;
 		}
 		/* :888-906 (leak_calc=false): photon hit the glass at the entrance */
-		free(cap_x);
-		free(cap_y);
 		return 2;
 	}
 
@@ -570,8 +582,6 @@ int orc_launch(const orc_optic *optic, orc_photon *photon, size_t n_energies, co
 		if (iesc != 1)
 			break;
 	}
-	free(cap_x);
-	free(cap_y);
 
 	/* :947-954 */
 	if ((iesc == -1) || (iesc == -3))
@@ -870,6 +880,18 @@ int orc_transmission(const orc_optic *optic, const orc_source *source,
                      uint64_t seed, int64_t slot0, int64_t n_slots, int n_threads, uint32_t max_attempts,
                      double *sum_weights, int64_t counters[4], double *img, double *exit_weights)
 {
+	return orc_transmission_fixed(optic, source, n_energies, energies, amu, scatf, seed, slot0, n_slots, n_threads,
+	                              max_attempts, sum_weights, counters, img, exit_weights, NULL);
+}
+
+/* The same driver; sumw_fixed (2 x n_energies words, may be NULL) also receives sum_j floor(w_j * 2^62) per energy as
+ * an exact 128-bit integer (lo, hi) -- the representation the GPU path accumulates in, so that totals of any number of
+ * slots can be compared, split and added without a rounding that depends on the order of the sum. */
+int orc_transmission_fixed(const orc_optic *optic, const orc_source *source,
+                     size_t n_energies, const double *energies, const double *amu, const double *scatf,
+                     uint64_t seed, int64_t slot0, int64_t n_slots, int n_threads, uint32_t max_attempts,
+                     double *sum_weights, int64_t counters[4], double *img, double *exit_weights, uint64_t *sumw_fixed)
+{
 	int failed = 0;
 	size_t e;
 	int64_t c;
@@ -884,6 +906,7 @@ int orc_transmission(const orc_optic *optic, const orc_source *source,
 		/* per-thread partials combined in thread order (the reference uses an omp critical, :973-980) */
 		double *part_w = calloc((size_t)n_threads * n_energies, sizeof(double));
 		int64_t *part_c = calloc((size_t)n_threads * 4, sizeof(int64_t));
+		unsigned __int128 *part_f = calloc((size_t)n_threads * n_energies, sizeof(unsigned __int128));
 		int t;
 #ifdef _OPENMP
 #pragma omp parallel num_threads(n_threads)
@@ -896,11 +919,12 @@ int orc_transmission(const orc_optic *optic, const orc_source *source,
 #endif
 			double *w = malloc(sizeof(double) * n_energies);
 			double *pw = part_w + (size_t)tid * n_energies;
+			unsigned __int128 *pf = part_f + (size_t)tid * n_energies;
 			int64_t *pc = part_c + (size_t)tid * 4;
 			int64_t j;
 			size_t ee;
 #ifdef _OPENMP
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 64)
 #endif
 			for (j = 0; j < n_slots; j++) {
 				uint32_t used = orc_one_slot(optic, source, n_energies, energies, amu, scatf, seed, slot0 + j,
@@ -916,6 +940,7 @@ int orc_transmission(const orc_optic *optic, const orc_source *source,
 				}
 				for (ee = 0; ee < n_energies; ee++) {
 					pw[ee] += w[ee];
+					pf[ee] += (unsigned __int128)(uint64_t)(w[ee] * 4611686018427387904.0);
 					if (exit_weights) exit_weights[(size_t)j*n_energies + ee] = w[ee];
 				}
 			}
@@ -925,8 +950,17 @@ int orc_transmission(const orc_optic *optic, const orc_source *source,
 			for (e = 0; e < n_energies; e++) sum_weights[e] += part_w[(size_t)t*n_energies + e];
 			for (c = 0; c < 4; c++) counters[c] += part_c[(size_t)t*4 + c];
 		}
+		if (sumw_fixed) {
+			for (e = 0; e < n_energies; e++) {
+				unsigned __int128 tot = 0;
+				for (t = 0; t < n_threads; t++) tot += part_f[(size_t)t*n_energies + e];
+				sumw_fixed[2*e] = (uint64_t)tot;
+				sumw_fixed[2*e + 1] = (uint64_t)(tot >> 64);
+			}
+		}
 		free(part_w);
 		free(part_c);
+		free(part_f);
 	}
 	return failed ? -1 : 0;
 }

@@ -155,6 +155,11 @@ int orc_transmission(const orc_optic *optic, const orc_source *source,
                      size_t n_energies, const double *energies, const double *amu, const double *scatf,
                      uint64_t seed, int64_t slot0, int64_t n_slots, int n_threads, uint32_t max_attempts,
                      double *sum_weights, int64_t counters[4], double *img, double *exit_weights);
+/* + sumw_fixed[2*n_energies] (may be NULL): per energy the exact 128-bit integer sum_j floor(w_j * 2^62) as (lo, hi) */
+int orc_transmission_fixed(const orc_optic *optic, const orc_source *source,
+                     size_t n_energies, const double *energies, const double *amu, const double *scatf,
+                     uint64_t seed, int64_t slot0, int64_t n_slots, int n_threads, uint32_t max_attempts,
+                     double *sum_weights, int64_t counters[4], double *img, double *exit_weights, uint64_t *sumw_fixed);
 
 /* same driver with leak_calc=true (src/polycap-source.c:799-879, 925-1032).  Leak events come back as malloc'd arrays
  * (orc_free) of n x (12 + n_energies) doubles: slot, attempt, then the record of orc_launch_one_leak; ordered by slot,

@@ -99,6 +99,8 @@ def lib():
                                        C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_uint32,
                                        c_double_p, c_int64_p, c_double_p, c_double_p]
         L.orc_transmission.restype = C.c_int
+        L.orc_transmission_fixed.argtypes = L.orc_transmission.argtypes + [C.POINTER(C.c_uint64)]
+        L.orc_transmission_fixed.restype = C.c_int
         L.orc_efficiencies.argtypes = [C.c_size_t, c_double_p, c_int64_p, c_double_p]
         L.orc_efficiencies.restype = None
         L.orc_trace_wall.argtypes = [C.POINTER(OpticS), C.POINTER(PhotonS), c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -338,16 +340,17 @@ def transmission(optic, source, energies, amu, scatf, seed, slot0, n_slots, n_th
             seed, slot0, n_slots, n_threads, max_attempts, _dp(sw), cnt.ctypes.data_as(c_int64_p),
             _dp(img) if images else None, _dp(ew) if images else None)
     leaks = {}
+    fixed = np.zeros((E.shape[0], 2), dtype=np.uint64)     # exact sum of floor(w * 2^62) per energy, (lo, hi); plain runs only
     if leak_calc:
         pe, pi = c_double_p(), c_double_p()
         ne, ni = C.c_int64(0), C.c_int64(0)
         rc = lib().orc_transmission_leak(*args, C.byref(pe), C.byref(ne), C.byref(pi), C.byref(ni))
         leaks = dict(ext=_records(pe, ne.value, 12 + E.shape[0]), int=_records(pi, ni.value, 12 + E.shape[0]))
     else:
-        rc = lib().orc_transmission(*args)
+        rc = lib().orc_transmission_fixed(*args, fixed.ctypes.data_as(C.POINTER(C.c_uint64)))
     eff = np.zeros_like(E)
     if cnt[0] + cnt[1] + cnt[2] > 0:
         lib().orc_efficiencies(E.shape[0], _dp(sw), cnt.ctypes.data_as(c_int64_p), _dp(eff))
-    return dict(rc=rc, sum_weights=sw, counters=cnt, efficiencies=eff, images=img, exit_weights=ew,
+    return dict(rc=rc, sum_weights=sw, sumw_fixed=fixed, counters=cnt, efficiencies=eff, images=img, exit_weights=ew,
                 i_exit=int(cnt[0]), not_entered=int(cnt[1]), not_transmitted=int(cnt[2]), sum_irefl=int(cnt[3]),
                 i_start=int(cnt[0] + cnt[1] + cnt[2]), **leaks)

@@ -10,7 +10,7 @@ The package is a thin Python layer over libpolycap.so (host C + hand-written HIP
 There is no CPU implementation of the trace path in this package.
 """
 from ._cabi import Problem, lib  # noqa: F401
-from .hip import TraceContext, HipError, device_count, efficiencies, fixed_to_double, IMG_FIELDS  # noqa: F401
+from .hip import TraceContext, TraceGroup, HipError, device_count, efficiencies, fixed_to_double, IMG_FIELDS  # noqa: F401
 from .decks import problem_from_inp, optical_constants  # noqa: F401
 
 __version__ = "1.2"

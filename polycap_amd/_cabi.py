@@ -142,6 +142,22 @@ def lib():
     L.pc_hip_transmission_records.restype = C.c_int
     L.pc_hip_phase_stats.argtypes = [C.c_void_p, c_int64_p]
     L.pc_hip_phase_stats.restype = C.c_int
+    L.pc_hip_device_synchronize.argtypes = [C.c_void_p]
+    L.pc_hip_device_synchronize.restype = C.c_int
+    L.pc_hip_group_create.argtypes = [P(ProblemS), C.c_int, P(C.c_int), P(C.c_void_p)]
+    L.pc_hip_group_create.restype = C.c_int
+    L.pc_hip_group_destroy.argtypes = [C.c_void_p]
+    L.pc_hip_group_destroy.restype = None
+    L.pc_hip_group_size.argtypes = [C.c_void_p]
+    L.pc_hip_group_size.restype = C.c_int
+    L.pc_hip_group_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.pc_hip_group_set_option.restype = C.c_int
+    L.pc_hip_group_run.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_uint32, C.c_int]
+    L.pc_hip_group_run.restype = C.c_int
+    L.pc_hip_group_images.argtypes = [C.c_void_p, P(ImagesS)]
+    L.pc_hip_group_images.restype = C.c_int
+    L.pc_hip_group_totals.argtypes = [C.c_void_p, C.c_int, c_double_p, c_int64_p, P(C.c_uint64), P(C.c_int), P(C.c_float)]
+    L.pc_hip_group_totals.restype = C.c_int
     L.pc_hip_efficiencies.argtypes = [C.c_size_t, c_double_p, c_int64_p, c_double_p]
     L.pc_hip_efficiencies.restype = None
     L.pc_hip_fixed_to_double.argtypes = [C.c_uint64, C.c_uint64]

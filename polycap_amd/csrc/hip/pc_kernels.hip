@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -1387,7 +1388,7 @@ static int pc_fetch_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const 
 		workers.run(pieces, planes, dst ? dst->exit_coord_weights : nullptr, rec, ne, raw);
 	};
 	size_t prev_done = 0, prev_n = 0;
-	int c = 0, part = 0;
+	int c = 0, part = 0, waited = -1;
 	for (size_t done = 0; done < (size_t)count; done += chunk, c++) {
 		const size_t n = ((size_t)count - done < chunk) ? (size_t)count - done : chunk;
 		const int b = c & 1;
@@ -1396,7 +1397,11 @@ static int pc_fetch_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const 
 			/* the last slot of the chunk decides which part has to be finished */
 			const long long last = first + (long long)(done + n) - 1;
 			while (part < ctx->n_parts - 1 && ctx->part_end[part] <= last) part++;
-			PC_HIP_CHECK(hipStreamWaitEvent(ctx->fetch_stream, ctx->ev_part[part], 0));
+			/* every part up to that one: consecutive parts run on two streams, so the event of part p says nothing
+			 * about part p-1, whose tail a chunk that straddles the boundary also reads */
+			for (int q = waited + 1; q <= part; q++)
+				PC_HIP_CHECK(hipStreamWaitEvent(ctx->fetch_stream, ctx->ev_part[q], 0));
+			if (part > waited) waited = part;
 		}
 		PC_HIP_CHECK(hipMemcpyAsync(h_buf, ctx->d_img + ((size_t)first + done)*rec, n*rec*sizeof(double), hipMemcpyDeviceToHost,
 		                            ctx->n_parts > 1 ? ctx->fetch_stream : ctx->stream));
@@ -1433,7 +1438,17 @@ void pc_hip_efficiencies(size_t n_energies, const double *sum_weights, const int
 		efficiencies[i] = (sum_weights[i] / ((double)sum_iexit+(double)sum_not_transmitted)) * open_area;
 }
 
+int pc_hip_device_synchronize(pc_hip_ctx *ctx)
+{
+	if (!ctx) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_device_synchronize: ctx must not be NULL");
+	PC_HIP_CHECK(hipSetDevice(ctx->device));
+	PC_HIP_CHECK(hipDeviceSynchronize());
+	return PC_HIP_OK;
+}
+
 } /* extern "C" */
+
+#include "pc_group.h"
 
 static int pc_transmission_enqueue_leak(pc_hip_ctx *ctx)
 {

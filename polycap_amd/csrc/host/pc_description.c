@@ -11,6 +11,7 @@
 
 #include <errno.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -171,6 +172,8 @@ void pc_ctx_cache_clear(pc_ctx_cache *c)
 		return;
 	if (c->ctx)
 		pc_hip_ctx_destroy(c->ctx);
+	if (c->group)
+		pc_hip_group_destroy(c->group);
 	free(c->energies);
 	memset(c, 0, sizeof(*c));
 }
@@ -185,19 +188,22 @@ void pc_set_hip_error(polycap_error **error, const char *caller, int status)
 	polycap_set_error(error, code, "%s: GPU trace path failed (%d): %s", caller, status, pc_hip_last_error());
 }
 
-/* Returns the HIP context for (description, energies[, source]); rebuilt only when one of them changed.
- * The device is POLYCAP_HIP_DEVICE (default 0).  There is no CPU fallback: failure is reported to the caller. */
-pc_hip_ctx *pc_ctx_for(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
-	const polycap_source *source, const char *caller, polycap_error **error)
+/* Returns the HIP context -- or, with a device list, the group of contexts -- for (description, energies[, source]);
+ * rebuilt only when one of them changed.  The device is POLYCAP_HIP_DEVICE (default 0).  There is no CPU fallback:
+ * failure is reported to the caller. */
+static int pc_cache_prepare(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
+	const polycap_source *source, int n_devices, const int *devices, const char *caller, polycap_error **error)
 {
 	double src[8] = {1., 1., 1., 0., 0., 0., 0., 0.};
 	if (source != NULL) {
 		src[0] = source->d_source; src[1] = source->src_x; src[2] = source->src_y; src[3] = source->src_sigx;
 		src[4] = source->src_sigy; src[5] = source->src_shiftx; src[6] = source->src_shifty; src[7] = source->hor_pol;
 	}
-	if (c->ctx != NULL && c->n_energies == n_energies && memcmp(c->energies, energies, sizeof(double)*n_energies) == 0 &&
+	const int same_target = (n_devices == 0) ? (c->ctx != NULL)
+		: (c->group != NULL && c->n_devices == n_devices && memcmp(c->devices, devices, sizeof(int)*(size_t)n_devices) == 0);
+	if (same_target && c->n_energies == n_energies && memcmp(c->energies, energies, sizeof(double)*n_energies) == 0 &&
 	    c->has_source == (source != NULL) && memcmp(c->src, src, sizeof(src)) == 0)
-		return c->ctx;
+		return 0;
 	pc_ctx_cache_clear(c);
 
 	double *amu = malloc(sizeof(double)*n_energies);
@@ -207,14 +213,32 @@ pc_hip_ctx *pc_ctx_for(pc_ctx_cache *c, polycap_description *description, size_t
 		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "%s: could not allocate memory for optical constants -> %s", caller, strerror(errno));
 		free(amu); free(scatf);
 		pc_ctx_cache_clear(c);
-		return NULL;
+		return -1;
 	}
 	int synthetic = 0;
 	if (pc_optconst_scatf(description->nelem, description->iz, description->wi, description->density,
 	                      n_energies, energies, amu, scatf, &synthetic, error) != 0) {
 		free(amu); free(scatf);
 		pc_ctx_cache_clear(c);
-		return NULL;
+		return -1;
+	}
+	if (synthetic) {
+		/* The reference takes these constants from xraylib.  Without libxrl the built-in table is exact only where the
+		 * reference's own tests pin it (10 keV; 40 and 80 keV are fits to its leak answers): say so once, on stderr, unless
+		 * the caller chose the table explicitly (POLYCAP_OPTCONST=builtin). */
+		static int warned = 0;
+		const char *choice = getenv("POLYCAP_OPTCONST");
+		if (!warned && !(choice != NULL && strcmp(choice, "builtin") == 0)) {
+			double lo = energies[0], hi = energies[0];
+			for (size_t i = 1; i < n_energies; i++) {
+				if (energies[i] < lo) lo = energies[i];
+				if (energies[i] > hi) hi = energies[i];
+			}
+			warned = 1;
+			fprintf(stderr, "polycap (%s): xraylib (libxrl) not found; optical constants for %g-%g keV come from the %s provider, "
+				"which is approximate away from 10 keV.  Install xraylib for the reference's values, or set POLYCAP_OPTCONST=builtin to accept the table.\n",
+				caller, lo, hi, pc_optconst_provider());
+		}
 	}
 	pc_hip_problem p;
 	memset(&p, 0, sizeof(p));
@@ -224,20 +248,47 @@ pc_hip_ctx *pc_ctx_for(pc_ctx_cache *c, polycap_description *description, size_t
 	p.n_energies = n_energies; p.energies = energies; p.amu = amu; p.scatf = scatf;
 	p.d_source = src[0]; p.src_x = src[1]; p.src_y = src[2]; p.src_sigx = src[3]; p.src_sigy = src[4];
 	p.src_shiftx = src[5]; p.src_shifty = src[6]; p.hor_pol = src[7];
-	int device = 0;
-	const char *env = getenv("POLYCAP_HIP_DEVICE");
-	if (env != NULL && *env != '\0')
-		device = atoi(env);
-	int status = pc_hip_ctx_create(&p, device, &c->ctx);
+	int status;
+	if (n_devices == 0) {
+		int device = 0;
+		const char *env = getenv("POLYCAP_HIP_DEVICE");
+		if (env != NULL && *env != '\0')
+			device = atoi(env);
+		status = pc_hip_ctx_create(&p, device, &c->ctx);
+	} else {
+		status = pc_hip_group_create(&p, n_devices, devices, &c->group);
+		c->n_devices = n_devices;
+		memcpy(c->devices, devices, sizeof(int)*(size_t)n_devices);
+	}
 	free(amu); free(scatf);
 	if (status != PC_HIP_OK) {
 		pc_set_hip_error(error, caller, status);
 		pc_ctx_cache_clear(c);
-		return NULL;
+		return -1;
 	}
 	c->n_energies = n_energies;
 	memcpy(c->energies, energies, sizeof(double)*n_energies);
 	c->has_source = (source != NULL);
 	memcpy(c->src, src, sizeof(src));
+	return 0;
+}
+
+pc_hip_ctx *pc_ctx_for(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
+	const polycap_source *source, const char *caller, polycap_error **error)
+{
+	if (pc_cache_prepare(c, description, n_energies, energies, source, 0, NULL, caller, error) != 0)
+		return NULL;
 	return c->ctx;
+}
+
+pc_hip_group *pc_group_for(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
+	const polycap_source *source, int n_devices, const int *devices, const char *caller, polycap_error **error)
+{
+	if (n_devices < 1 || n_devices > 64 || devices == NULL) {
+		polycap_set_error(error, POLYCAP_ERROR_INVALID_ARGUMENT, "%s: POLYCAP_HIP_DEVICES must name between 1 and 64 devices", caller);
+		return NULL;
+	}
+	if (pc_cache_prepare(c, description, n_energies, energies, source, n_devices, devices, caller, error) != 0)
+		return NULL;
+	return c->group;
 }

@@ -13,7 +13,10 @@
  *     attenuation coefficients on the standard grid (log-log interpolation, Si K edge at 1.8389 keV) and a
  *     coarse anomalous-scattering table, both normalised so that the one point the reference's tests pin
  *     (O 53 % / Si 47 %, 2.23 g/cm3, 10 keV: scatf = 0.503696, amu = 42.544635; tests/photon.c:75-76) is
- *     reproduced.  Away from 10 keV the built-in values are approximations and are reported as synthetic.
+ *     reproduced.  Away from 10 keV the built-in values are approximations and are reported as synthetic
+ *     (the C API prints a one-time warning on stderr, pc_ctx_for; the Python layer exposes prob.synthetic_constants).
+ *     The 40 keV (amu, scatf) and 80 keV (amu) entries are FITS to the reference's leak test vectors (tests/leaks.c),
+ *     not XCOM data: they pin the leak path's geometry and bookkeeping, not the physics at those energies.
  * POLYCAP_OPTCONST=builtin skips provider 1.
  */
 #define _GNU_SOURCE

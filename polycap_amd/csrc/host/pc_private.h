@@ -26,6 +26,9 @@ struct _polycap_profile {
 /* cached device context for one (description, energy grid, source) combination */
 typedef struct {
 	pc_hip_ctx *ctx;
+	pc_hip_group *group;      /* POLYCAP_HIP_DEVICES: one context per listed device instead of `ctx` */
+	int n_devices;
+	int devices[64];
 	size_t n_energies;
 	double *energies;
 	int has_source;
@@ -155,6 +158,9 @@ bool pc_leak_list_copy(polycap_leak **src, int64_t n_src, polycap_leak ***leaks,
 void pc_ctx_cache_clear(pc_ctx_cache *c);
 pc_hip_ctx *pc_ctx_for(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
 	const polycap_source *source, const char *caller, polycap_error **error);
+/* the same for a device list (POLYCAP_HIP_DEVICES): a group of contexts, one per entry */
+pc_hip_group *pc_group_for(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
+	const polycap_source *source, int n_devices, const int *devices, const char *caller, polycap_error **error);
 void pc_set_hip_error(polycap_error **error, const char *caller, int status);
 
 #endif

@@ -16,6 +16,7 @@
 #include <errno.h>
 #include <inttypes.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -317,6 +318,38 @@ static uint64_t pc_env_u64(const char *name, uint64_t fallback, int *present)
 	return (uint64_t)v;
 }
 
+/* POLYCAP_HIP_DEVICES = "all" or a comma-separated list of device indices (an index may repeat).  *n = 0 when unset. */
+static int pc_env_devices(int devices[64], int *n, polycap_error **error)
+{
+	*n = 0;
+	const char *env = getenv("POLYCAP_HIP_DEVICES");
+	if (env == NULL || *env == '\0')
+		return 0;
+	if (strcmp(env, "all") == 0) {
+		int count = pc_hip_device_count();
+		if (count < 1) {
+			polycap_set_error_literal(error, POLYCAP_ERROR_RUNTIME, "polycap_source_get_transmission_efficiencies: POLYCAP_HIP_DEVICES=all but no HIP device is visible (the trace path has no CPU fallback)");
+			return -1;
+		}
+		if (count > 64) count = 64;
+		for (int k = 0; k < count; k++) devices[k] = k;
+		*n = count;
+		return 0;
+	}
+	const char *p = env;
+	while (*p != '\0') {
+		char *end = NULL;
+		long v = strtol(p, &end, 10);
+		if (end == p || v < 0 || *n >= 64 || (*end != ',' && *end != '\0')) {
+			polycap_set_error(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_transmission_efficiencies: cannot parse POLYCAP_HIP_DEVICES=%s (all, or up to 64 comma-separated device indices)", env);
+			return -1;
+		}
+		devices[(*n)++] = (int)v;
+		p = (*end == ',') ? end + 1 : end;
+	}
+	return 0;
+}
+
 /* POLYCAP_TIMING=1: stage times of polycap_source_get_transmission_efficiencies on stderr */
 static double pc_now_ms(void)
 {
@@ -363,9 +396,25 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 
 	const size_t ne = source->n_energies;
 	const int timing = getenv("POLYCAP_TIMING") != NULL;
+	/* Extensions of the reference call, all through the environment so that the signature stays the reference's:
+	 *   POLYCAP_HIP_DEVICES=all | i,j,...  the photon loop is sharded over these devices from this one process (the
+	 *       reference's OpenMP team, :697-745, becomes a team of GPUs); totals are summed by one RCCL all-reduce (:973-980)
+	 *   POLYCAP_IMAGES=0                   histogram-only result: efficiencies and counts, no per-photon planes (at 1e8
+	 *       photons x 291 energies the weight plane alone is 233 GB); the start/exit getters then report no events */
+	int devices[64], n_devices = 0;
+	if (pc_env_devices(devices, &n_devices, error) != 0)
+		return NULL;
+	const char *img_env = getenv("POLYCAP_IMAGES");
+	const int keep_images = !(img_env != NULL && strcmp(img_env, "0") == 0);
+	if (leak_calc && !keep_images) {
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_transmission_efficiencies: POLYCAP_IMAGES=0 cannot be combined with leak_calc (leak events are per-photon data)");
+		return NULL;
+	}
+	if (leak_calc && n_devices > 1)
+		n_devices = 1;      /* leak runs keep their event lists on one device: the first of the list */
 	double t_stage[8];
 	t_stage[0] = pc_now_ms();
-	polycap_transmission_efficiencies *eff = pc_transeff_alloc(source, (size_t)n_photons, "polycap_source_get_transmission_efficiencies", error);
+	polycap_transmission_efficiencies *eff = pc_transeff_alloc(source, keep_images ? (size_t)n_photons : 0, "polycap_source_get_transmission_efficiencies", error);
 	double *sum_weights = malloc(sizeof(double)*ne);
 	if (eff == NULL || sum_weights == NULL) {
 		if (eff != NULL)
@@ -375,8 +424,20 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 		return NULL;
 	}
 
-	pc_hip_ctx *ctx = pc_ctx_for(&source->cache, description, ne, source->energies, source, "polycap_source_get_transmission_efficiencies", error);
-	if (ctx == NULL) {
+	pc_hip_ctx *ctx = NULL;
+	pc_hip_group *group = NULL;
+	if (n_devices > 0 && !leak_calc)
+		group = pc_group_for(&source->cache, description, ne, source->energies, source, n_devices, devices, "polycap_source_get_transmission_efficiencies", error);
+	else {
+		if (n_devices == 1) {
+			/* a one-entry list selects the device like POLYCAP_HIP_DEVICE */
+			char buf[16];
+			snprintf(buf, sizeof(buf), "%d", devices[0]);
+			setenv("POLYCAP_HIP_DEVICE", buf, 1);
+		}
+		ctx = pc_ctx_for(&source->cache, description, ne, source->energies, source, "polycap_source_get_transmission_efficiencies", error);
+	}
+	if (ctx == NULL && group == NULL) {
 		free(sum_weights);
 		polycap_transmission_efficiencies_free(eff);
 		return NULL;
@@ -390,29 +451,46 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 	uint32_t max_attempts = (uint32_t)pc_env_u64("POLYCAP_MAX_ATTEMPTS", 1u << 20, NULL);
 
 	int64_t counters[6] = {0, 0, 0, 0, 0, 0};
+	int status;
 	/* big plain runs are traced in four parts so that the images of a finished part cross PCIe while the next part runs */
-	int status = pc_hip_set_option(ctx, "run_parts", (!leak_calc && n_photons >= 2000000) ? (int)pc_env_u64("POLYCAP_RUN_PARTS", 4, NULL) : 1);
-	if (status == PC_HIP_OK)
-		status = leak_calc ? pc_hip_transmission_run_leak(ctx, seed, 0, n_photons, max_attempts, 1)
-		                   : pc_hip_transmission_run(ctx, seed, 0, n_photons, max_attempts, 1);
+	const int parts = (!leak_calc && keep_images && n_photons >= 2000000) ? (int)pc_env_u64("POLYCAP_RUN_PARTS", 4, NULL) : 1;
+	if (group != NULL) {
+		status = pc_hip_group_set_option(group, "run_parts", parts);
+		if (status == PC_HIP_OK)
+			status = pc_hip_group_run(group, seed, n_photons, max_attempts, keep_images);
+	} else {
+		status = pc_hip_set_option(ctx, "run_parts", parts);
+		if (status == PC_HIP_OK)
+			status = leak_calc ? pc_hip_transmission_run_leak(ctx, seed, 0, n_photons, max_attempts, 1)
+			                   : pc_hip_transmission_run(ctx, seed, 0, n_photons, max_attempts, keep_images);
+	}
 	t_stage[2] = pc_now_ms();
 	t_stage[3] = t_stage[2];
-	if (status == PC_HIP_OK) {
+	if (status == PC_HIP_OK && keep_images) {
 		pc_transeff_prefault(eff, (size_t)n_photons);    /* the kernel is running: fault the result pages in meanwhile */
 		t_stage[3] = pc_now_ms();
 		pc_hip_images dst;
 		pc_transeff_plane_pointers(eff, &dst);
-		status = pc_hip_transmission_images(ctx, 0, n_photons, &dst);    /* waits part by part (a leak run: for all of it) */
+		status = (group != NULL) ? pc_hip_group_images(group, &dst)
+		                         : pc_hip_transmission_images(ctx, 0, n_photons, &dst);    /* waits part by part (a leak run: for all of it) */
 	}
 	t_stage[4] = pc_now_ms();
-	if (status == PC_HIP_OK)
-		status = pc_hip_transmission_wait(ctx, NULL);
-	if (status == PC_HIP_OK)
-		status = pc_hip_transmission_totals(ctx, sum_weights, counters, NULL);
+	int reduced_by = 0;
+	if (status == PC_HIP_OK) {
+		if (group != NULL) {
+			const char *r = getenv("POLYCAP_RCCL");      /* 0: host sum, 1: RCCL or fail; default: RCCL when possible */
+			status = pc_hip_group_totals(group, (r != NULL && *r != '\0') ? atoi(r) : -1, sum_weights, counters, NULL, &reduced_by, NULL);
+		} else {
+			status = pc_hip_transmission_wait(ctx, NULL);
+			if (status == PC_HIP_OK)
+				status = pc_hip_transmission_totals(ctx, sum_weights, counters, NULL);
+		}
+	}
 	t_stage[5] = pc_now_ms();
 	if (timing)
-		fprintf(stderr, "polycap timing [ms]: alloc+context %.1f, enqueue %.1f, prefault %.1f, images (incl. waiting for the kernel) %.1f, totals %.1f\n",
-			t_stage[1] - t_stage[0], t_stage[2] - t_stage[1], t_stage[3] - t_stage[2], t_stage[4] - t_stage[3], t_stage[5] - t_stage[4]);
+		fprintf(stderr, "polycap timing [ms]: alloc+context %.1f, enqueue %.1f, prefault %.1f, images (incl. waiting for the kernel) %.1f, totals %.1f%s\n",
+			t_stage[1] - t_stage[0], t_stage[2] - t_stage[1], t_stage[3] - t_stage[2], t_stage[4] - t_stage[3], t_stage[5] - t_stage[4],
+			group != NULL ? (reduced_by ? " (devices summed by RCCL all-reduce)" : " (devices summed on the host)") : "");
 	if (status == PC_HIP_OK && leak_calc)
 		status = pc_transeff_fetch_leaks(eff, ctx);      /* reference :925-1032 */
 	if (status != PC_HIP_OK) {
@@ -431,6 +509,8 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 	printf("iexit: %" PRId64 ", no enter: %" PRId64 ", no trans: %" PRId64 "\n", sum_iexit, sum_not_entered, sum_not_transmitted);
 
 	pc_transeff_finish(eff, sum_weights, counters);
+	if (!keep_images)
+		eff->images->i_exit = 0;     /* no per-photon planes were kept: the exit/start getters report no events */
 	free(sum_weights);
 	return eff;
 }

@@ -363,6 +363,11 @@ bool polycap_transmission_efficiencies_get_exit_data(polycap_transmission_effici
 		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_exit_data: no photon start events in efficiencies");
 		return false;
 	}
+	if (im->i_exit == 0) {
+		/* only a histogram-only result (POLYCAP_IMAGES=0) has started photons and no exit planes */
+		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_exit_data: no photon exit events in efficiencies (histogram-only result)");
+		return false;
+	}
 	const size_t n = (size_t)im->i_exit, ne = efficiencies->n_energies;
 	*exit_coords = malloc(sizeof(polycap_vector3) * n);
 	*exit_direction = malloc(sizeof(polycap_vector3) * n);

@@ -64,6 +64,12 @@ class TraceContext:
         if st != _cabi.PC_HIP_OK:
             raise HipError("pc_hip_set_option", st)
 
+    def device_synchronize(self):
+        """hipDeviceSynchronize on the context's device (every stream)."""
+        st = self._L.pc_hip_device_synchronize(self._h)
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_device_synchronize", st)
+
     # -- polycap_photon_launch for a batch of explicit photons
     def launch_photons(self, start, direction, elecv, leak_calc=False):
         """leak_calc=True: polycap_photon_launch(..., leak_calc=true); the events are then available from leaks()"""
@@ -193,6 +199,66 @@ class TraceContext:
             r.update(self.images(0, n_slots))
         if leak_calc:
             r["ext"], r["int"] = self.leaks()
+        return r
+
+
+class TraceGroup:
+    """One problem on several devices driven from this process (pc_hip_group_*): contiguous slot ranges per member, one
+    RCCL all-reduce (or the identical host sum) of the totals.  `devices` may repeat an index."""
+
+    def __init__(self, problem, devices):
+        self.problem = problem
+        self._L = _cabi.lib()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        st = self._L.pc_hip_group_create(C.byref(problem.s), len(devices), devs, C.byref(h))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_group_create", st)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pc_hip_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_option(self, name, value):
+        st = self._L.pc_hip_group_set_option(self._h, name.encode(), int(value))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_group_set_option", st)
+
+    def transmission(self, seed, n_slots, max_attempts=1 << 20, keep_images=False, reduce=-1):
+        """reduce: -1 automatic (RCCL when the devices are distinct and librccl loads), 0 host sum, 1 RCCL or fail"""
+        st = self._L.pc_hip_group_run(self._h, int(seed), int(n_slots), int(max_attempts), int(bool(keep_images)))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_group_run", st)
+        ne = self.problem.n_energies
+        r = {}
+        if keep_images:
+            planes = np.zeros((17, n_slots))
+            nrefl = np.zeros(n_slots, dtype=np.int64)
+            w = np.zeros((n_slots, ne))
+            s = _cabi.images_struct(planes, nrefl, w)
+            st = self._L.pc_hip_group_images(self._h, C.byref(s))
+            if st != _cabi.PC_HIP_OK:
+                raise HipError("pc_hip_group_images", st)
+            planes[15] = nrefl
+            r.update(images=planes.T.copy(), exit_weights=w, nrefl=nrefl)
+        sw = np.zeros(ne)
+        cnt = np.zeros(6, dtype=np.int64)
+        fx = np.zeros(2 * ne, dtype=np.uint64)
+        by, ms = C.c_int(0), C.c_float(0)
+        st = self._L.pc_hip_group_totals(self._h, int(reduce), dptr(sw), cnt.ctypes.data_as(c_int64_p),
+                                         fx.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(by), C.byref(ms))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_group_totals", st)
+        r.update(sum_weights=sw, counters=cnt, sumw_fixed=fx.reshape(ne, 2), reduced_by_rccl=bool(by.value), kernel_ms=float(ms.value),
+                 i_exit=int(cnt[0]), i_start=int(cnt[0] + cnt[1] + cnt[2]), efficiencies=efficiencies(sw, cnt))
         return r
 
 

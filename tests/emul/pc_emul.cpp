@@ -10,6 +10,9 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "pc_problem.h"
 #include "pc_leak.h"
@@ -180,6 +183,58 @@ int emul_transmission_leak(const pc_hip_problem *p, uint64_t seed, int64_t slot0
 	}
 	*n_records = (int64_t)cursor;
 	*stack_overflow = cx.stack_overflow;
+	return 0;
+}
+
+/* the driver loop of src/polycap-source.c:744-884 (leak_calc=false) for slots [slot0, slot0 + n_slots) on the host compile
+ * of the device code -- photon for photon what pc_trace_kernel computes (tests/test_gpu_parity.py checks that bit for
+ * bit), with the kernel's exact fixed-point sums.  counters = {iexit, not_entered, not_transmitted, sum_irefl};
+ * sumw_fixed = (lo, hi) of sum floor(w * 2^62) (single energy); per_slot (optional) = weight, i_refl, attempts used per slot.
+ * OpenMP over slots: used by the bias study (scripts/parity_bias.py) next to the oracle. */
+int emul_transmission(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int64_t n_slots, uint32_t max_attempts,
+                      int n_threads, int64_t *counters, uint64_t *sumw_fixed, double *per_slot)
+{
+	Emul E;
+	int r = setup(p, 0, E);
+	if (r) return r;
+	if (p->n_energies != 1) return -1;
+	int64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+	unsigned __int128 tot = 0;
+#ifdef _OPENMP
+	if (n_threads < 1) n_threads = omp_get_max_threads();
+#pragma omp parallel num_threads(n_threads) reduction(+: c0, c1, c2, c3)
+#endif
+	{
+		unsigned __int128 mine = 0;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 64)
+#endif
+		for (int64_t j = 0; j < n_slots; j++) {
+			for (uint32_t attempt = 0; attempt < max_attempts; attempt++) {
+				pc_start s;
+				if (E.t.pm.generic_src) pc_sample_photon<true>(E.t.pm, seed, (uint64_t)(slot0 + j), attempt, s);
+				else pc_sample_photon<false>(E.t.pm, seed, (uint64_t)(slot0 + j), attempt, s);
+				pc_photon<1> ph; ph.wmem = nullptr; ph.wstride = 0;
+				int rc = run_photon(E, ph, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez, nullptr);
+				int ok = 0;
+				if (rc == 0) c2++;
+				else if (rc == 2) c1++;
+				else if (rc == 1) ok = pc_in_exit_window(E.t.pm, ph);
+				if (ok) {
+					c0++; c3 += ph.irefl;
+					mine += (unsigned __int128)(uint64_t)(ph.w[0] * 4611686018427387904.0);
+					if (per_slot) { per_slot[3*j] = ph.w[0]; per_slot[3*j + 1] = (double)ph.irefl; per_slot[3*j + 2] = (double)(attempt + 1); }
+					break;
+				}
+			}
+		}
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+		tot += mine;
+	}
+	counters[0] = c0; counters[1] = c1; counters[2] = c2; counters[3] = c3;
+	sumw_fixed[0] = (uint64_t)tot; sumw_fixed[1] = (uint64_t)(tot >> 64);
 	return 0;
 }
 

@@ -22,7 +22,7 @@ def lib():
                 os.path.join(_ROOT, "polycap_amd", "csrc", "hip", "pc_leak.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
-                                   "-ffp-contract=off", "-mfma",   # same IEEE operation sequence as the gfx950 build (fma only where written)
+                                   "-ffp-contract=off", "-mfma", "-fopenmp",   # same IEEE operation sequence as the gfx950 build (fma only where written)
                                    "-I" + os.path.join(_ROOT, "include"),
                                    "-I" + os.path.join(_ROOT, "polycap_amd", "csrc", "hip"),
                                    "-o", so, srcs[0]])
@@ -38,6 +38,9 @@ def lib():
         L.emul_transmission_leak.argtypes = [C.POINTER(ProblemS), C.c_uint64, C.c_int64, C.c_int64, C.c_uint32, C.c_int, C.c_int64,
                                              c_double_p, c_int64_p, c_double_p, c_double_p, c_int64_p, C.POINTER(C.c_int32)]
         L.emul_transmission_leak.restype = C.c_int
+        L.emul_transmission.argtypes = [C.POINTER(ProblemS), C.c_uint64, C.c_int64, C.c_int64, C.c_uint32, C.c_int,
+                                        c_int64_p, C.POINTER(C.c_uint64), c_double_p]
+        L.emul_transmission.restype = C.c_int
         L.emul_sample.argtypes = [C.POINTER(ProblemS), C.c_uint64, C.c_int64, c_int64_p, C.POINTER(C.c_uint32), c_double_p]
         L.emul_sample.restype = C.c_int
         _LIB = L
@@ -62,6 +65,21 @@ def launch_batch(problem, start, direction, elecv, literal=False, use_regs=True)
         raise RuntimeError("emul_launch_batch failed: %d" % r)
     return dict(rc=rc, weights=w, exit_coords=ec, exit_dir=ed, exit_elecv=ee, i_refl=ir, d_travel=dt,
                 fast_nodes=int(stats[0]), events=int(stats[1]))
+
+
+def transmission(problem, seed, slot0, n_slots, max_attempts=1 << 20, n_threads=0, per_slot=False):
+    """Driver loop on the host compile of the device code (single energy): counters, exact fixed-point weight sum, efficiency."""
+    cnt = np.zeros(4, dtype=np.int64)
+    fixed = np.zeros(2, dtype=np.uint64)
+    ps = np.zeros((n_slots, 3)) if per_slot else None
+    r = lib().emul_transmission(C.byref(problem.s), seed, slot0, n_slots, max_attempts, n_threads, cnt.ctypes.data_as(c_int64_p),
+                                fixed.ctypes.data_as(C.POINTER(C.c_uint64)), dptr(ps) if per_slot else None)
+    if r:
+        raise RuntimeError("emul_transmission failed: %d" % r)
+    exact = int(fixed[0]) + (int(fixed[1]) << 64)
+    i_start = int(cnt[0] + cnt[1] + cnt[2])
+    return dict(counters=cnt, sumw_exact=exact, i_start=i_start, i_exit=int(cnt[0]), sum_irefl=int(cnt[3]),
+                efficiency=(exact / 2.0**62) / i_start if i_start else 0.0, per_slot=ps)
 
 
 def sample(problem, seed, slots, attempts):

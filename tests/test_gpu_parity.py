@@ -491,7 +491,7 @@ def test_image_fetch_paths_agree_on_a_multi_energy_run(pa, oracle):
     assert np.array_equal(a["counters"][:4], b["counters"][:4]) and np.array_equal(a["sumw_fixed"], b["sumw_fixed"])
 
 
-@pytest.mark.parametrize("deck, sig_rough, n", [("xos1", None, 100_000_000), ("ellip_l9", 5e-8, 20_000_000)])
+@pytest.mark.parametrize("deck, sig_rough, n", [("xos1", None, 100_000_000), ("ellip_l9", 5.0, 20_000_000)])
 def test_energy_sweep_properties_at_scale(pa, deck, sig_rough, n):
     """BASELINE configs C3 (xos1, 1e8 exit photons: full size) and C5 (ellip_l9 with 5 A roughness; 2e7 of its 1.25e8 per GPU) on
     the decks' own 291-energy grid 1-30 keV, histogram only as at
@@ -533,3 +533,109 @@ def test_energy_sweep_properties_at_scale(pa, deck, sig_rough, n):
     with pa.TraceContext(prob) as ctx:
         sweep = ctx.transmission(77, 0, 200_000)
     assert sweep["not_entered"] == single["not_entered"]
+
+
+def test_c5_deck_roughness_vs_oracle(pa, oracle):
+    """BASELINE config C5 on the deck itself: example/ellip_l9.inp, its 291-point grid, sig_rough = 5 (Angstrom, the unit
+    of the reference: include/polycap-description.h:45, example/dub_foc.inp:1; used raw at src/polycap-capil.c:626).
+    The driver against the oracle on identical seeds, and the roughness must cost transmission -- a unit slip
+    (5e-8 "cm") makes exp(-(1.01358 E alpha sigma)^2) == 1 and fails here."""
+    import os
+    from tests.conftest import EXAMPLE
+    path = os.path.join(EXAMPLE, "ellip_l9.inp")
+    rough = pa.problem_from_inp(path, sig_rough=5.0)
+    smooth = pa.problem_from_inp(path)
+    assert rough.n_energies == 291 and smooth.sig_rough == 0.0 and rough.sig_rough == 5.0
+    n = 20000
+    with pa.TraceContext(rough) as ctx:
+        g = ctx.transmission(77, 0, n)
+        g10 = ctx.transmission(78, 0, 400_000)
+    with pa.TraceContext(smooth) as ctx:
+        s10 = ctx.transmission(78, 0, 400_000)
+    E = np.asarray(rough.energies)
+    k10 = int(np.argmin(np.abs(E - 10.0)))
+    # survey probe of the compiled reference: 0.1256 with 5 A against 0.1345 without at 10 keV (SURVEY.md section 6), -6.6 %
+    ratio = g10["efficiencies"] / s10["efficiencies"]
+    assert 0.90 < ratio[k10] < 0.96, ratio[k10]
+    assert np.all(ratio[E >= 3.0] < 0.995) and np.all(np.diff(ratio[(E >= 5.0) & (E <= 20.0)]) < 2e-3)
+    assert abs(g10["efficiencies"][k10] - 0.1256) < 0.004 and abs(s10["efficiencies"][k10] - 0.1345) < 0.004
+    optic = oracle.Optic(rough.z, rough.cap, rough.ext, 5.0, rough.n_cap, rough.density)
+    o = oracle.transmission(optic, oracle.make_source(*rough.source), rough.energies, rough.amu, rough.scatf, 77, 0, n)
+    assert g["i_exit"] == n == o["i_exit"]
+    tol = 3.0 / np.sqrt(o["i_start"])
+    assert abs(g["i_start"] - o["i_start"]) / o["i_start"] < tol
+    lo = E <= 15.0          # beyond, a handful of photons carry the sum and the relative error grows (1 % at 30 keV)
+    assert np.all(np.abs(g["efficiencies"] / o["efficiencies"] - 1.0)[lo] < tol)
+    assert np.all(np.abs(g["efficiencies"] / o["efficiencies"] - 1.0) < 0.05)
+
+
+def test_device_group_is_bit_identical_to_one_device(pa, oracle):
+    """pc_hip_group_*: the slot range sharded over several device contexts of one process (the same GPU listed more than
+    once on a one-GPU box) gives the totals and every image plane of the single-context run, bit for bit; the totals of
+    a one-device group summed through RCCL (ncclCommInitAll + ncclAllReduce of the 32-bit limbs) equal the host sum."""
+    optic, src, prob, _ = make_pair(oracle, "xos1", source=(2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.0))
+    n = 300_001
+    with pa.TraceContext(prob) as ctx:
+        one = ctx.transmission(41, 0, n, keep_images=True)
+    for devices in ([0, 0], [0, 0, 0]):
+        with pa.TraceGroup(prob, devices) as grp:
+            g = grp.transmission(41, n, keep_images=True)
+        assert not g["reduced_by_rccl"]                 # a device twice: host limb sum
+        assert np.array_equal(g["counters"][:4], one["counters"][:4]) and np.array_equal(g["sumw_fixed"], one["sumw_fixed"])
+        assert np.array_equal(g["images"], one["images"], equal_nan=True) and np.array_equal(g["exit_weights"], one["exit_weights"])
+        assert np.array_equal(g["efficiencies"], one["efficiencies"])
+    with pa.TraceGroup(prob, [0]) as grp:
+        r = grp.transmission(41, n, reduce=1)           # RCCL or fail: a communicator of one rank
+        h = grp.transmission(41, n, reduce=0)
+    assert r["reduced_by_rccl"] and not h["reduced_by_rccl"]
+    assert np.array_equal(r["counters"], h["counters"]) and np.array_equal(r["sumw_fixed"], h["sumw_fixed"])
+    assert np.array_equal(r["sumw_fixed"], one["sumw_fixed"])
+    # seven energies: the limb vector has 6 + 4 x 7 entries
+    optic, src, prob7, _ = make_pair(oracle, "ellip", energies=(5.0, 8.0, 11.0, 14.0, 17.0, 20.0, 25.0))
+    with pa.TraceContext(prob7) as ctx:
+        one7 = ctx.transmission(3, 0, 50_000)
+    with pa.TraceGroup(prob7, [0]) as grp:
+        r7 = grp.transmission(3, 50_000, reduce=1)
+    with pa.TraceGroup(prob7, [0, 0]) as grp:
+        h7 = grp.transmission(3, 50_000)
+    assert np.array_equal(r7["sumw_fixed"], one7["sumw_fixed"]) and np.array_equal(h7["sumw_fixed"], one7["sumw_fixed"])
+    assert np.array_equal(r7["counters"][:4], one7["counters"][:4]) and np.array_equal(h7["counters"][:4], one7["counters"][:4])
+
+
+def test_c_api_multi_device_and_histogram_only(pa, monkeypatch):
+    """polycap_source_get_transmission_efficiencies with POLYCAP_HIP_DEVICES (the photon loop sharded over a device list,
+    reference src/polycap-source.c:697-745, totals summed as :973-980) and POLYCAP_IMAGES=0 (histogram-only result):
+    two "devices" equal one bit for bit through the public C API, and BASELINE C3 at its full size (xos1.inp, 291
+    energies, 1e8 exit photons: 233 GB of weights with images) runs through the drop-in call."""
+    import os
+    from polycap_amd import capi
+    from tests.conftest import EXAMPLE
+    monkeypatch.setenv("POLYCAP_SEED", "77")
+    src = capi.Source.new_from_file(os.path.join(EXAMPLE, "xos1.inp"))
+
+    def run(n, **env):
+        for k in ("POLYCAP_HIP_DEVICES", "POLYCAP_IMAGES", "POLYCAP_RCCL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        return src.get_transmission_efficiencies(-1, n)
+
+    a = run(200_000)
+    b = run(200_000, POLYCAP_HIP_DEVICES="0,0")
+    c = run(200_000, POLYCAP_HIP_DEVICES="0", POLYCAP_RCCL="1")
+    assert np.array_equal(a.data[1], b.data[1]) and np.array_equal(a.data[1], c.data[1])
+    assert np.array_equal(a.exit_weights, b.exit_weights) and np.array_equal(a.n_refl, b.n_refl)
+    assert np.array_equal(a.d_travel, b.d_travel)
+    h = run(200_000, POLYCAP_HIP_DEVICES="0,0", POLYCAP_IMAGES="0")
+    assert np.array_equal(a.data[1], h.data[1])
+    with pytest.raises(ValueError):
+        h.exit_weights                                    # no per-photon planes in a histogram-only result
+    del a, b, c, h
+    # C3 at full size through the drop-in call, against the thin-ABI run of the same streams
+    full = run(100_000_000, POLYCAP_HIP_DEVICES="0,0", POLYCAP_IMAGES="0")
+    E, eff = full.data
+    assert len(E) == 291 and np.all((eff > 0) & (eff < 1)) and np.all(np.diff(eff[E >= 10.0]) < 0)
+    prob = pa.problem_from_inp(os.path.join(EXAMPLE, "xos1.inp"))
+    with pa.TraceContext(prob) as ctx:
+        t = ctx.transmission(77, 0, 100_000_000)
+    assert np.array_equal(eff, t["efficiencies"])
