@@ -211,12 +211,15 @@ pc_trace_kernel(pc_kargs a)
 				if (state == LS_MARCH && ph.first)
 					state = pc_march_step(T, Pm, ph);
 				for (int b = 0; b < a.march_burst; b++) {
+					unsigned int lanes_in_burst = 0;     /* lanes that take each of these steps (scheduler statistics) */
 #pragma unroll
-					for (int u = 0; u < PC_MARCH_UNROLL; u++)
+					for (int u = 0; u < PC_MARCH_UNROLL; u++) {
+						lanes_in_burst += (unsigned)__popcll(__ballot(state == LS_MARCH));
 						if (state == LS_MARCH)
 							state = pc_march_step_hot(T, Pm, ph);
+					}
 					const int cM = __popcll(__ballot(state == LS_MARCH));
-					st_march += PC_MARCH_UNROLL; st_march_l += PC_MARCH_UNROLL*(unsigned)cM;
+					st_march += PC_MARCH_UNROLL; st_march_l += lanes_in_burst;
 					if (cM == 0) break;
 					if (cM < a.event_threshold && (cM != nM || do_new || nE > 0)) break;
 				}

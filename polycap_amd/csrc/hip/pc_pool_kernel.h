@@ -192,11 +192,14 @@ pc_trace_pool_kernel(pc_kargs a)
 			/* ---------------- MARCH: PQ_UNROLL certified steps */
 			if (L.state == LS_MARCH && ph.first)
 				L.state = pc_march_step(T, Pm, ph);
+			unsigned int lanes_in_burst = 0;     /* lanes that take each of the burst's steps (scheduler statistics) */
 #pragma unroll
-			for (int u = 0; u < PQ_UNROLL; u++)
+			for (int u = 0; u < PQ_UNROLL; u++) {
+				lanes_in_burst += (unsigned)__popcll(__ballot(L.state == LS_MARCH));
 				if (L.state == LS_MARCH)
 					L.state = pc_march_step_hot(T, Pm, ph);
-			st_march += PQ_UNROLL; st_march_l += PQ_UNROLL*(unsigned)__popcll(__ballot(L.state == LS_MARCH));
+			}
+			st_march += PQ_UNROLL; st_march_l += lanes_in_burst;
 		} else if (X == 1) {
 			/* ---------------- EVENT */
 			st_event += 1; st_event_l += (unsigned)__popcll(__ballot(L.state == LS_EVENT));

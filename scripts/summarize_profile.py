@@ -1,4 +1,4 @@
-"""Condenses gpurun_out/prof_<tag>_* (rocprofv3 csv) into profiles/r01/<tag>_*.{csv,json}."""
+"""Condenses gpurun_out/prof_<tag>_* (rocprofv3 csv) into profiles/<round>/<tag>_*.{csv,json}:  python scripts/summarize_profile.py <tag> [round, default r02]"""
 import collections
 import csv
 import glob
@@ -9,7 +9,7 @@ import sys
 
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out_dir = os.path.join(root, "profiles", "r01")
+out_dir = os.path.join(root, "profiles", sys.argv[2] if len(sys.argv) > 2 else "r02")
 os.makedirs(out_dir, exist_ok=True)
 ks = glob.glob(os.path.join(root, "gpurun_out", "prof_%s_kt" % tag, "*", "*_kernel_stats.csv"))
 if ks:
