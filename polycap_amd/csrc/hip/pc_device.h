@@ -63,6 +63,10 @@ struct pc_params {
 	double cap0, ext0;
 };
 
+/* block-certificate margins of one start node (pc_march_ok): base and chord deviation of zh for strides PC_L1 and PC_L2;
+ * +inf where the stride does not fit before the end of the profile */
+struct pc_marg4 { float mb1, md1, mb2, md2; };
+
 /* profile tables.  z/cap/zh/cap2 are the MARCH tables (LDS on the device), ext is only read on events. */
 struct pc_tables {
 	const double *z;
@@ -73,7 +77,7 @@ struct pc_tables {
 	const double *idz;   /* 1 / (z[i+1] - z[i]) */
 	const double *ext;
 	/* block certificates (see pc_march_ok): for stride L1 / L2, margin base and chord deviation of zh, rounded up */
-	const float *mb1, *md1, *mb2, *md2;
+	const struct pc_marg4 *mg;   /* margin base and chord deviation of zh of both strides, packed per start node: one 16-byte read */
 };
 
 #ifndef PC_L1
@@ -439,15 +443,14 @@ PC_HD int pc_march_ok(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph
 	const int i0 = ph.i;
 	int lv = 0;
 	double marg = Pm.adj;
-	if (cap >= 1 && i0 + PC_L1 <= Pm.nmax) {
-		double kd = ph.kn * (double)T.md1[i0];
-		double m1 = fma(kd, Pm.two_rmax + kd, (double)T.mb1[i0]);
-		if (ph.C0 < -m1) { lv = 1; marg = m1; }
-	}
-	if (cap >= 2 && i0 + PC_L2 <= Pm.nmax) {
-		double kd = ph.kn * (double)T.md2[i0];
-		double m2 = fma(kd, Pm.two_rmax + kd, (double)T.mb2[i0]);
-		if (ph.C0 < -m2) { lv = 2; marg = m2; }
+	{
+		/* a stride that does not fit before the end of the profile has an infinite margin: no index test needed */
+		const pc_marg4 g = T.mg[i0];
+		const double kd1 = ph.kn * (double)g.md1, kd2 = ph.kn * (double)g.md2;
+		const double m1 = fma(kd1, Pm.two_rmax + kd1, (double)g.mb1);
+		const double m2 = fma(kd2, Pm.two_rmax + kd2, (double)g.mb2);
+		if (cap >= 1 && ph.C0 < -m1) { lv = 1; marg = m1; }
+		if (cap >= 2 && ph.C0 < -m2) { lv = 2; marg = m2; }
 	}
 	const int L = (lv == 0) ? 1 : ((lv == 1) ? PC_L1 : PC_L2);
 	const int i1 = i0 + L;

@@ -132,7 +132,7 @@ pc_trace_kernel(pc_kargs a)
 	constexpr bool EXPLICIT = (MODE == PC_MODE_EXPLICIT);
 	/* static LDS with a compile-time pitch: table reads become ds_read with immediate offsets */
 	__shared__ double lds[6*PITCH];
-	__shared__ float ldsf[4*PITCH];
+	__shared__ pc_marg4 ldsg[PITCH];
 	/* NE == 0: per-workgroup exact weight sums, (lo, hi) per energy, when they fit (a.lds_acc); else global atomics */
 	extern __shared__ unsigned long long l_acc[];
 	const int npts = a.pm.nmax + 1;
@@ -144,7 +144,7 @@ pc_trace_kernel(pc_kargs a)
 		l_cap2[k] = a.g_cap2[k];
 		l_hexd[k] = a.g_hexd[k];
 		l_idz[k] = a.g_idz[k];
-		ldsf[k] = a.g_mb1[k]; ldsf[PITCH + k] = a.g_md1[k]; ldsf[2*PITCH + k] = a.g_mb2[k]; ldsf[3*PITCH + k] = a.g_md2[k];
+		ldsg[k] = pc_marg4{a.g_mb1[k], a.g_md1[k], a.g_mb2[k], a.g_md2[k]};
 	}
 	if (NE != 1 && a.lds_acc)
 		for (int k = threadIdx.x; k < 2*a.pm.n_energies; k += blockDim.x) l_acc[k] = 0ull;
@@ -159,7 +159,7 @@ pc_trace_kernel(pc_kargs a)
 	__syncthreads();
 	pc_tables T;
 	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.hexd = l_hexd; T.idz = l_idz; T.ext = a.g_ext;
-	T.mb1 = ldsf; T.md1 = ldsf + PITCH; T.mb2 = ldsf + 2*PITCH; T.md2 = ldsf + 3*PITCH;
+	T.mg = ldsg;
 	const long long rec = PC_N_FIELDS + (long long)a.pm.n_energies;   /* doubles per image record */
 	const pc_params &Pm = a.pm;
 	const int ne = (NE > 0) ? NE : Pm.n_energies;
@@ -737,6 +737,12 @@ struct pc_hip_ctx {
 	int img_valid = 0;
 	double *d_wscratch = nullptr;
 	size_t wscratch_elems = 0;
+	/* explicit-photon calls (polycap_photon_launch, polycap_source_get_photon): one device buffer and one pinned host
+	 * buffer, kept between calls, so that a single photon costs two copies and a launch instead of ten copies and
+	 * as many allocations */
+	double *d_batch = nullptr, *h_batch = nullptr;
+	size_t batch_elems = 0;
+	bool h_batch_pinned = false;
 	long long run_slots = 0;
 	int run_pending = 0;
 	float last_ms = 0.f;
@@ -904,6 +910,8 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->d_work) (void)hipFree(ctx->d_work);
 	if (ctx->ev_sync) (void)hipEventDestroy(ctx->ev_sync);
 	if (ctx->d_wscratch) (void)hipFree(ctx->d_wscratch);
+	if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+	if (ctx->h_batch) { if (ctx->h_batch_pinned) (void)hipHostFree(ctx->h_batch); else free(ctx->h_batch); }
 	if (ctx->d_leak_frames) (void)hipFree(ctx->d_leak_frames);
 	if (ctx->d_leak_records) (void)hipFree(ctx->d_leak_records);
 	if (ctx->d_leak_cursor) (void)hipFree(ctx->d_leak_cursor);
@@ -997,6 +1005,26 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	return PC_HIP_OK;
 }
 
+/* device + pinned host buffer of at least `elems` doubles for the explicit-photon calls */
+static int pc_batch_buffers(pc_hip_ctx *ctx, size_t elems)
+{
+	if (ctx->batch_elems >= elems) return PC_HIP_OK;
+	if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+	if (ctx->h_batch) { if (ctx->h_batch_pinned) (void)hipHostFree(ctx->h_batch); else free(ctx->h_batch); }
+	ctx->d_batch = ctx->h_batch = nullptr; ctx->batch_elems = 0;
+	const size_t want = elems < 4096 ? 4096 : elems + elems/4;
+	if (hipMalloc(&ctx->d_batch, want*sizeof(double)) != hipSuccess) { ctx->d_batch = nullptr; return pc_fail(PC_HIP_ERR_MEMORY, "explicit-photon batch: device allocation failed"); }
+	ctx->h_batch_pinned = true;
+	if (hipHostMalloc(&ctx->h_batch, want*sizeof(double), hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		ctx->h_batch_pinned = false;
+		ctx->h_batch = (double *)malloc(want*sizeof(double));
+		if (!ctx->h_batch) { (void)hipFree(ctx->d_batch); ctx->d_batch = nullptr; return pc_fail(PC_HIP_ERR_MEMORY, "explicit-photon batch: host allocation failed"); }
+	}
+	ctx->batch_elems = want;
+	return PC_HIP_OK;
+}
+
 static int pc_launch_photons_impl(pc_hip_ctx *ctx, int64_t n, const double *start_coords, const double *start_dir, const double *start_elecv,
                                   int32_t *rc, double *weights, double *exit_coords, double *exit_dir, double *exit_elecv,
                                   int64_t *i_refl, double *d_travel, int leak)
@@ -1007,10 +1035,14 @@ static int pc_launch_photons_impl(pc_hip_ctx *ctx, int64_t n, const double *star
 	PC_HIP_CHECK(hipSetDevice(ctx->device));
 	const size_t ne = (size_t)ctx->host.pm.n_energies;
 	const size_t N = (size_t)n;
-	/* one device buffer: 3 inputs [3N], rc [N ints padded], weights [N*ne], 3 outputs [3N], irefl [N], dtravel [N] */
-	size_t doubles = 9*N + N + N*ne + 9*N + N + N;
-	double *d = nullptr;
-	if (hipMalloc(&d, doubles*sizeof(double)) != hipSuccess) return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_launch_photons: device allocation failed");
+	/* one device buffer: 3 inputs [3N], rc [N ints padded], weights [N*ne], 3 outputs [3N], irefl [N], dtravel [N]; the pinned
+	 * host buffer mirrors it: one copy in (the inputs), one copy out (everything behind them) */
+	const size_t doubles = 9*N + N + N*ne + 9*N + N + N;
+	{
+		int st = pc_batch_buffers(ctx, doubles);
+		if (st) return st;
+	}
+	double *d = ctx->d_batch, *h = ctx->h_batch;
 	double *d_start = d, *d_dir = d + 3*N, *d_ev = d + 6*N;
 	int *d_rc = (int *)(d + 9*N);
 	double *d_w = d + 10*N, *d_ec = d_w + N*ne, *d_ed = d_ec + 3*N, *d_ee = d_ed + 3*N;
@@ -1019,9 +1051,10 @@ static int pc_launch_photons_impl(pc_hip_ctx *ctx, int64_t n, const double *star
 	int status = PC_HIP_OK;
 #define PC_LP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { status = pc_fail(PC_HIP_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e)); goto done; } } while (0)
 	{
-		PC_LP_CHECK(hipMemcpyAsync(d_start, start_coords, 3*N*sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-		PC_LP_CHECK(hipMemcpyAsync(d_dir, start_dir, 3*N*sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-		PC_LP_CHECK(hipMemcpyAsync(d_ev, start_elecv, 3*N*sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+		memcpy(h, start_coords, 3*N*sizeof(double));
+		memcpy(h + 3*N, start_dir, 3*N*sizeof(double));
+		memcpy(h + 6*N, start_elecv, 3*N*sizeof(double));
+		PC_LP_CHECK(hipMemcpyAsync(d, h, 9*N*sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 		PC_LP_CHECK(hipMemsetAsync(ctx->d_totals, 0, ctx->totals_bytes, ctx->stream));
 		pc_kargs a;
 		pc_fill_common(ctx, a);
@@ -1048,14 +1081,18 @@ static int pc_launch_photons_impl(pc_hip_ctx *ctx, int64_t n, const double *star
 			status = pc_launch_kernel<PC_MODE_EXPLICIT>(ctx, a, n);
 			if (status) goto done;
 		}
-		PC_LP_CHECK(hipMemcpyAsync(rc, d_rc, N*sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-		PC_LP_CHECK(hipMemcpyAsync(weights, d_w, N*ne*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-		PC_LP_CHECK(hipMemcpyAsync(exit_coords, d_ec, 3*N*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-		PC_LP_CHECK(hipMemcpyAsync(exit_dir, d_ed, 3*N*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-		PC_LP_CHECK(hipMemcpyAsync(exit_elecv, d_ee, 3*N*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-		PC_LP_CHECK(hipMemcpyAsync(i_refl, d_ir, N*sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-		PC_LP_CHECK(hipMemcpyAsync(d_travel, d_dt, N*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		PC_LP_CHECK(hipMemcpyAsync(h + 9*N, d + 9*N, (doubles - 9*N)*sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 		PC_LP_CHECK(hipStreamSynchronize(ctx->stream));
+		{
+			const double *o = h + 9*N;        /* rc (ints, padded to N doubles), weights, exit coords / dir / elecv, irefl, dtravel */
+			memcpy(rc, o, N*sizeof(int)); o += N;
+			memcpy(weights, o, N*ne*sizeof(double)); o += N*ne;
+			memcpy(exit_coords, o, 3*N*sizeof(double)); o += 3*N;
+			memcpy(exit_dir, o, 3*N*sizeof(double)); o += 3*N;
+			memcpy(exit_elecv, o, 3*N*sizeof(double)); o += 3*N;
+			memcpy(i_refl, o, N*sizeof(long long)); o += N;
+			memcpy(d_travel, o, N*sizeof(double));
+		}
 		/* The kernels work with the normalised electric vector (polycap_refl_polar normalises it in place at the first
 		 * reflection, src/polycap-capil.c:492-494); a photon that never reached a reflection keeps the caller's vector */
 		for (size_t j = 0; j < N; j++) {
@@ -1066,7 +1103,6 @@ static int pc_launch_photons_impl(pc_hip_ctx *ctx, int64_t n, const double *star
 	}
 done:
 #undef PC_LP_CHECK
-	(void)hipFree(d);
 	ctx->img_valid = 0;
 	return status;
 }
@@ -1091,26 +1127,26 @@ int pc_hip_sample_photons(pc_hip_ctx *ctx, uint64_t seed, int64_t n, const int64
 	if (n == 0) return PC_HIP_OK;
 	PC_HIP_CHECK(hipSetDevice(ctx->device));
 	const size_t N = (size_t)n;
-	long long *d_slots = nullptr; unsigned int *d_att = nullptr; double *d_out = nullptr;
-	int status = PC_HIP_OK;
-	if (hipMalloc(&d_slots, N*sizeof(long long)) != hipSuccess || hipMalloc(&d_att, N*sizeof(unsigned int)) != hipSuccess ||
-	    hipMalloc(&d_out, 12*N*sizeof(double)) != hipSuccess) {
-		status = pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_sample_photons: device allocation failed");
-	} else {
-		hipError_t e = hipMemcpy(d_slots, slots, N*sizeof(long long), hipMemcpyHostToDevice);
-		if (e == hipSuccess) e = hipMemcpy(d_att, attempts, N*sizeof(unsigned int), hipMemcpyHostToDevice);
-		if (e == hipSuccess) {
-			hipLaunchKernelGGL(pc_sample_kernel, dim3((unsigned)((N + 255)/256)), dim3(256), 0, ctx->stream,
-			                   ctx->host.pm, (unsigned long long)seed, (long long)n, d_slots, d_att, d_out);
-			e = hipGetLastError();
-		}
-		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-		if (e == hipSuccess) e = hipMemcpy(out, d_out, 12*N*sizeof(double), hipMemcpyDeviceToHost);
-		if (e != hipSuccess) status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_sample_photons: ") + hipGetErrorString(e));
+	/* layout in the batch buffers: slots [N int64], attempts [N uint32, padded to N/2 + 1 doubles], out [12 N] */
+	const size_t off_att = N, off_out = N + N/2 + 1, total = off_out + 12*N;
+	{
+		int st = pc_batch_buffers(ctx, total);
+		if (st) return st;
 	}
-	if (d_slots) (void)hipFree(d_slots);
-	if (d_att) (void)hipFree(d_att);
-	if (d_out) (void)hipFree(d_out);
+	double *d = ctx->d_batch, *h = ctx->h_batch;
+	memcpy(h, slots, N*sizeof(long long));
+	memcpy(h + off_att, attempts, N*sizeof(unsigned int));
+	int status = PC_HIP_OK;
+	hipError_t e = hipMemcpyAsync(d, h, off_out*sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(pc_sample_kernel, dim3((unsigned)((N + 255)/256)), dim3(256), 0, ctx->stream,
+		                   ctx->host.pm, (unsigned long long)seed, (long long)n, (const long long *)d, (const unsigned int *)(d + off_att), d + off_out);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(h + off_out, d + off_out, 12*N*sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	if (e != hipSuccess) status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_sample_photons: ") + hipGetErrorString(e));
+	else memcpy(out, h + off_out, 12*N*sizeof(double));
 	return status;
 }
 

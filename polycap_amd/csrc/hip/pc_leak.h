@@ -551,7 +551,7 @@ PC_HD int pc_wall_probe(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 				const double r0 = T.cap[i0], r1 = T.cap[i1];
 				reach = (r0 > r1) ? r0 : r1;
 			} else {
-				reach = 0.5*Pm.two_rmax + kn * (double)((lv == 2) ? T.md2[i0] : T.md1[i0]);
+				reach = 0.5*Pm.two_rmax + kn * (double)((lv == 2) ? T.mg[i0].md2 : T.mg[i0].md1);
 			}
 			reach += 1.e-7 * (0.5*Pm.two_rmax);
 			if (cxm*cxm + cym*cym > reach*reach) {

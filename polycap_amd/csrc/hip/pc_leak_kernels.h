@@ -38,7 +38,7 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 {
 	constexpr bool EXPLICIT = (MODE == PC_MODE_EXPLICIT);
 	__shared__ double lds[7*PITCH];
-	__shared__ float ldsf[4*PITCH];
+	__shared__ pc_marg4 ldsg[PITCH];
 	const int npts = a.pm.nmax + 1;
 	for (int k = threadIdx.x; k < npts; k += blockDim.x) {
 		lds[k] = a.g_z[k];
@@ -48,13 +48,13 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 		lds[4*PITCH + k] = a.g_hexd[k];
 		lds[5*PITCH + k] = a.g_idz[k];
 		lds[6*PITCH + k] = a.g_ext[k];
-		ldsf[k] = a.g_mb1[k]; ldsf[PITCH + k] = a.g_md1[k]; ldsf[2*PITCH + k] = a.g_mb2[k]; ldsf[3*PITCH + k] = a.g_md2[k];
+		ldsg[k] = pc_marg4{a.g_mb1[k], a.g_md1[k], a.g_mb2[k], a.g_md2[k]};
 	}
 	__syncthreads();
 	pc_tables T;
 	T.z = lds; T.cap = lds + PITCH; T.zh = lds + 2*PITCH; T.cap2 = lds + 3*PITCH; T.hexd = lds + 4*PITCH; T.idz = lds + 5*PITCH;
 	T.ext = lds + 6*PITCH;
-	T.mb1 = ldsf; T.md1 = ldsf + PITCH; T.mb2 = ldsf + 2*PITCH; T.md2 = ldsf + 3*PITCH;
+	T.mg = ldsg;
 	const pc_params &Pm = a.pm;
 	const int ne = Pm.n_energies;
 	const long long rec = PC_N_FIELDS + (long long)ne;

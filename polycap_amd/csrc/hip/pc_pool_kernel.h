@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(PQ_BLOCK, PQ_MIN_WAVES)
 pc_trace_pool_kernel(pc_kargs a)
 {
 	__shared__ double lds[6*PQ_PITCH];
-	__shared__ float ldsf[4*PQ_PITCH];
+	__shared__ pc_marg4 ldsg[PQ_PITCH];
 	__shared__ double l_pool[PQ_WAVES*PQ_R*PQ_P];
 	__shared__ unsigned short l_est[PQ_WAVES*PC_WAVE];
 	__shared__ unsigned char l_sel[PQ_WAVES*PC_WAVE];
@@ -138,7 +138,7 @@ pc_trace_pool_kernel(pc_kargs a)
 		l_cap2[k] = a.g_cap2[k];
 		l_hexd[k] = a.g_hexd[k];
 		l_idz[k] = a.g_idz[k];
-		ldsf[k] = a.g_mb1[k]; ldsf[PQ_PITCH + k] = a.g_md1[k]; ldsf[2*PQ_PITCH + k] = a.g_mb2[k]; ldsf[3*PQ_PITCH + k] = a.g_md2[k];
+		ldsg[k] = pc_marg4{a.g_mb1[k], a.g_md1[k], a.g_mb2[k], a.g_md2[k]};
 	}
 	const int lane = threadIdx.x & (PC_WAVE - 1);
 	const int wave = threadIdx.x / PC_WAVE;
@@ -149,7 +149,7 @@ pc_trace_pool_kernel(pc_kargs a)
 	__syncthreads();
 	pc_tables T;
 	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.hexd = l_hexd; T.idz = l_idz; T.ext = a.g_ext;
-	T.mb1 = ldsf; T.md1 = ldsf + PQ_PITCH; T.mb2 = ldsf + 2*PQ_PITCH; T.md2 = ldsf + 3*PQ_PITCH;
+	T.mg = ldsg;
 	const long long rec = PC_N_FIELDS + 1;
 	const pc_params &Pm = a.pm;
 
@@ -195,7 +195,7 @@ pc_trace_pool_kernel(pc_kargs a)
 			unsigned int lanes_in_burst = 0;     /* lanes that take each of the burst's steps (scheduler statistics) */
 #pragma unroll
 			for (int u = 0; u < PQ_UNROLL; u++) {
-				lanes_in_burst += (unsigned)__popcll(__ballot(L.state == LS_MARCH));
+				if ((u & 3) == 0) lanes_in_burst += 4u*(unsigned)__popcll(__ballot(L.state == LS_MARCH));   /* sampled every 4th step */
 				if (L.state == LS_MARCH)
 					L.state = pc_march_step_hot(T, Pm, ph);
 			}

@@ -28,6 +28,7 @@
 struct pc_host_tables {
 	std::vector<double> z, cap, zh, cap2, hexd, idz, ext;
 	std::vector<float> mb1, md1, mb2, md2;   /* block-certificate tables for strides PC_L1, PC_L2 */
+	std::vector<pc_marg4> mg;                /* the same, packed per node (what pc_march_ok reads) */
 	std::vector<pc_energy_const> ec;
 	std::vector<double> amu;                 /* linear attenuation coefficient per energy (leak path) */
 	pc_params pm;
@@ -117,6 +118,8 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 			md[i] = fd;
 		}
 	}
+	t.mg.resize(n);
+	for (int i = 0; i < n; i++) t.mg[i] = pc_marg4{t.mb1[i], t.md1[i], t.mb2[i], t.md2[i]};
 	pm.bnd_thresh = ratio + 1e-9;
 
 	t.ec.resize(p->n_energies);

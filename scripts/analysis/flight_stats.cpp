@@ -41,7 +41,7 @@ extern "C" int flight_stats(const pc_hip_problem *p, int64_t n, const double *st
 	if (pc_build_tables(p, t, err)) return 1;
 	pc_tables T;
 	T.z = t.z.data(); T.cap = t.cap.data(); T.zh = t.zh.data(); T.cap2 = t.cap2.data(); T.hexd = t.hexd.data(); T.idz = t.idz.data(); T.ext = t.ext.data();
-	T.mb1 = t.mb1.data(); T.md1 = t.md1.data(); T.mb2 = t.mb2.data(); T.md2 = t.md2.data();
+	T.mg = t.mg.data();
 	std::vector<Lev> lev(nlev);
 	for (int l = 0; l < nlev; l++) build_level(p, t, strides[l], lev[l]);
 	const pc_params &Pm = t.pm;

@@ -32,7 +32,7 @@ int setup(const pc_hip_problem *p, int literal, Emul &E)
 	E.t.pm.literal = literal;
 	E.T.z = E.t.z.data(); E.T.cap = E.t.cap.data(); E.T.zh = E.t.zh.data();
 	E.T.cap2 = E.t.cap2.data(); E.T.hexd = E.t.hexd.data(); E.T.idz = E.t.idz.data(); E.T.ext = E.t.ext.data();
-	E.T.mb1 = E.t.mb1.data(); E.T.md1 = E.t.md1.data(); E.T.mb2 = E.t.mb2.data(); E.T.md2 = E.t.md2.data();
+	E.T.mg = E.t.mg.data();
 	return 0;
 }
 

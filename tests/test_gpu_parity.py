@@ -639,3 +639,42 @@ def test_c_api_multi_device_and_histogram_only(pa, monkeypatch):
     with pa.TraceContext(prob) as ctx:
         t = ctx.transmission(77, 0, 100_000_000)
     assert np.array_equal(eff, t["efficiencies"])
+
+
+def test_reference_loop_check_get_photon_launch_vs_driver(pa, known):
+    """The reference's own consistency check of the path (tests/source.c:306-340, tests/python.py:279-301): a hand-rolled
+    loop of polycap_source_get_photon(rng seeded 20000) + polycap_photon_launch through the public API until 30000
+    photons are transmitted, against the curve of polycap_source_get_transmission_efficiencies, within 0.0075 at all
+    seven energies.  Every iteration is two C-API calls = two kernel launches on one photon (that is what the API is):
+    the loop is bounded to a minute, the measured per-photon latency is printed."""
+    import time
+    from polycap_amd import capi
+    t = known["transmission_curve"]
+    prof = capi.Profile(capi.Profile.ELLIPSOIDAL, 9., 0.2065, 0.0585, 0.00035, 9.9153e-5, 1000., 0.5)
+    desc = capi.Description(prof, 0.0, 200000, {"O": 53.0, "Si": 47.0}, 2.23)
+    energies = np.array(t["energies"], dtype=np.float64)
+    src = capi.Source(desc, t["d_source"], t["src_x"], t["src_y"], t["src_sigx"], t["src_sigy"], t["src_shiftx"],
+                      t["src_shifty"], t["hor_pol"], energies)
+    eff = src.get_transmission_efficiencies(-1, 30000)
+    curve = eff.data[1]
+    rng = capi.Rng(20000)
+    w_tot = np.zeros(7)
+    phot_ini = phot_transm = 0
+    t0 = time.perf_counter()
+    while phot_transm < 30000:
+        photon = src.get_photon(rng)
+        try:
+            w = photon.launch(energies)
+        except ValueError:          # return code -2: not in the entrance window (tests/source.c:329)
+            continue
+        phot_ini += 1
+        if w is not None:
+            assert np.all((w >= 0.) & (w <= 1.))
+            w_tot += w
+            phot_transm += 1
+        assert time.perf_counter() - t0 < 120., "the per-photon API loop is too slow"
+    dt = time.perf_counter() - t0
+    w_tot /= phot_ini
+    print("loop check: %d launched, %d transmitted in %.1f s (%.0f us per get_photon + launch); loop %s driver %s"
+          % (phot_ini, phot_transm, dt, 1e6 * dt / phot_ini, np.round(w_tot, 4), np.round(curve, 4)))
+    assert np.all(np.abs(curve - w_tot) <= 0.0075)
