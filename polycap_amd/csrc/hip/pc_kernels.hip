@@ -40,6 +40,9 @@
 #define PC_MARCH_UNROLL 8      /* march steps between two ballots of the burst loop (4: 32.5 ms, 8: 31.9 ms, 12: 33.1 ms; scripts/ab_flags.sh) */
 #endif
 #define PC_KE 5                /* energies per lane whose weights are in flight together in a cooperative sweep */
+#ifndef PC_KB
+#define PC_KB 4                /* reflections of a photon that wait for one sweep of its weights (many-energy kernel) */
+#endif
 #ifndef PC_CHUNK
 #define PC_CHUNK 128           /* slots a wave takes from the global counter at a time */
 #endif
@@ -88,6 +91,8 @@ struct pc_kargs {
 	int new_threshold;
 	int lds_acc;                  /* NE == 0: accumulate weight sums in LDS (2*n_energies u64 of dynamic LDS) */
 	int lds_ec;                   /* NE == 0: per-energy constants staged in LDS behind the sums (6*n_energies doubles) */
+	int lds_pend;                 /* NE == 0, more than 32 energies: reflections wait in LDS (PC_KB x 3 doubles per lane, behind the
+	                               * constants) and a photon's weights are swept once per PC_KB reflections */
 	int pool_event_min;           /* pool kernel: photons waiting for an EVENT phase that make it run before anything else */
 	int pool_refill;              /* pool kernel: lanes that must be free before a march burst tops itself up from the pool */
 	double *wscratch;             /* NE==0: n_energies * total_threads */
@@ -150,11 +155,9 @@ pc_trace_kernel(pc_kargs a)
 		for (int k = threadIdx.x; k < 2*a.pm.n_energies; k += blockDim.x) l_acc[k] = 0ull;
 	/* NE == 0: the per-energy constants of the cooperative sweeps, staged behind the sums when they fit (a.lds_ec):
 	 * every reflection of every photon reads all 6*n_energies of them */
-	const double *ecs = a.ec_soa;
 	if (NE == 0 && a.lds_ec) {
 		double *l_ec = (double *)(l_acc + 2*a.pm.n_energies);
 		for (int k = threadIdx.x; k < 6*a.pm.n_energies; k += blockDim.x) l_ec[k] = a.ec_soa[k];
-		ecs = l_ec;
 	}
 	__syncthreads();
 	pc_tables T;
@@ -176,6 +179,7 @@ pc_trace_kernel(pc_kargs a)
 	ph.rc = 0;
 
 	int state = LS_NEED_SLOT;
+	int npend = 0;                /* NE == 0, a.lds_pend: reflections of this lane's photon waiting in l_pend */
 	long long slot = -1;          /* relative slot index in [0, n_slots) */
 	unsigned int attempt = 0;
 	double cosalpha0 = 0.;         /* start_electric_vector . start_direction: projection constants of src/polycap-source.c:789-796 */
@@ -191,6 +195,71 @@ pc_trace_kernel(pc_kargs a)
 
 	/* wave-uniform scheduler statistics (diagnostics: lane utilisation per phase type) */
 	unsigned long long st_march = 0, st_march_l = 0, st_event = 0, st_event_l = 0, st_new = 0, st_new_l = 0;
+
+	/* Many energies (a.lds_pend): a reflection only pushes its geometry (cos theta, (E.s)^2, |n x d|^2: the rest of
+	 * pc_refl_geom follows from them by the expressions that made it) and the photon flies on as if it had survived; its
+	 * weights are swept once per PC_KB reflections -- one load and one store per energy instead of PC_KB, every energy
+	 * still multiplied in the reference's order, so the weights are the same bits.  The sweep finds the first waiting
+	 * reflection that absorbs the photon (no weight >= 1e-4 left) or fails (return -1): the photon then ends there, as in
+	 * the reference, and what it did afterwards is dropped (a photon that ends with rc -1/0/1 is swept before it is
+	 * finalised, so nothing speculative is ever counted). */
+	double *const l_pend = (NE == 0 && a.lds_pend) ? (double *)(l_acc + 2*a.pm.n_energies) + 6*a.pm.n_energies : nullptr;
+	auto flush = [&](unsigned long long mF) {
+		const double *ecs = (const double *)(l_acc + 2*a.pm.n_energies);      /* a.lds_pend implies a.lds_ec */
+		const long long wave_gtid0 = gtid - lane;
+		const int wave_t0 = (int)(threadIdx.x - lane);
+		while (mF) {
+			const int p = __ffsll((long long)mF) - 1;
+			mF &= mF - 1ull;
+			const int n = __shfl(npend, p, PC_WAVE);
+			const int wset_p = __shfl(ph.wset, p, PC_WAVE);
+			const double *gq = l_pend + (size_t)(wave_t0 + p)*(3*PC_KB);
+			double *wp = a.wscratch + (wave_gtid0 + p)*(long long)ne;
+			unsigned int badbits = 0, keepbits = 0;
+			for (int e0 = 0; e0 < ne; e0 += PC_WAVE*PC_KE) {
+				double wv[PC_KE];
+#pragma unroll
+				for (int k = 0; k < PC_KE; k++) {
+					const int e = e0 + k*PC_WAVE + lane;
+					wv[k] = (wset_p && e < ne) ? wp[e] : 1.0;
+				}
+#pragma unroll
+				for (int k = 0; k < PC_KE; k++) {
+					const int e = e0 + k*PC_WAVE + lane;
+					if (e < ne) {
+						pc_energy_const ec;
+						ec.n_re = ecs[e]; ec.n_im = ecs[ne + e];
+						ec.ninv2_re = ecs[2*ne + e]; ec.ninv2_im = ecs[3*ne + e];
+						ec.rough_c = ecs[4*ne + e]; ec.valid = ecs[5*ne + e];
+						int dead = 0;       /* the reference stops at the first energy that fails; later reflections are moot */
+						for (int r = 0; r < n; r++) {
+							pc_refl_geom gp;
+							gp.alfa = gq[3*r]; gp.es2 = gq[3*r + 1]; gp.sd2 = gq[3*r + 2];
+							gp.st2 = fma(-gp.alfa, gp.alfa, 1.0);
+							gp.ep2 = gp.sd2 - gp.es2;
+							if (!dead) {
+								const int rr = pc_reflect_energy(ec, gp, wv[k]);
+								if (rr < 0) { badbits |= 1u << r; dead = 1; }
+								if (rr > 0) keepbits |= 1u << r;
+							}
+						}
+						wp[e] = wv[k];
+					}
+				}
+			}
+			/* first waiting reflection that ends the photon: an error at any energy, or no energy left above 1e-4 */
+			int fail = -1, fail_rc = 0;
+			for (int r = n - 1; r >= 0; r--) {
+				const int anybad = __any((badbits >> r) & 1u), anykeep = __any((keepbits >> r) & 1u);
+				if (anybad || !anykeep) { fail = r; fail_rc = anybad ? -1 : 0; }
+			}
+			if (lane == p) {
+				npend = 0;
+				ph.wset = 1;
+				if (fail >= 0) { state = LS_DONE; ph.rc = fail_rc; }
+			}
+		}
+	};
 
 	for (;;) {
 		const unsigned long long mM = __ballot(state == LS_MARCH);
@@ -247,105 +316,125 @@ pc_trace_kernel(pc_kargs a)
 						state = st;
 					}
 				}
-				unsigned long long mP = __ballot(pend == 1);
-				const long long wave_gtid0 = gtid - lane;
-				if (ne <= 32) {
-					/* up to 32 energies: the wave is split into 64/G groups of G = 16 or 32 lanes and sweeps that many
-					 * pending photons per pass (lane = photon group x energy); four passes are in flight together so that
-					 * the latency of their weight loads (the weights live in HBM/L2) is paid once per batch, not per pass */
-					const int G = (ne <= 16) ? 16 : 32, PP = PC_WAVE / G;
-					const int sub = lane / G, e = lane - sub*G;
-					const unsigned long long gm = (G == 32) ? 0xffffffffull : 0xffffull;
-					pc_energy_const ec;
-					ec.n_re = ec.n_im = ec.ninv2_re = ec.ninv2_im = ec.rough_c = ec.valid = 0.;
-					if (e < ne) {
-						ec.n_re = ecs[e]; ec.n_im = ecs[ne + e];
-						ec.ninv2_re = ecs[2*ne + e]; ec.ninv2_im = ecs[3*ne + e];
-						ec.rough_c = ecs[4*ne + e]; ec.valid = ecs[5*ne + e];
-					}
+				/* the sweep is instantiated once per address space of the per-energy constants (LDS copy or global table): with one
+				 * merged pointer the compiler has to use flat loads, which are several times slower than ds_read for LDS data */
+				auto sweep = [&](const double *ecs) {
+					unsigned long long mP = __ballot(pend == 1);
+					const long long wave_gtid0 = gtid - lane;
+					if (ne <= 32) {
+						/* up to 32 energies: the wave is split into 64/G groups of G = 16 or 32 lanes and sweeps that many
+						 * pending photons per pass (lane = photon group x energy); four passes are in flight together so that
+						 * the latency of their weight loads (the weights live in HBM/L2) is paid once per batch, not per pass */
+						const int G = (ne <= 16) ? 16 : 32, PP = PC_WAVE / G;
+						const int sub = lane / G, e = lane - sub*G;
+						const unsigned long long gm = (G == 32) ? 0xffffffffull : 0xffffull;
+						pc_energy_const ec;
+						ec.n_re = ec.n_im = ec.ninv2_re = ec.ninv2_im = ec.rough_c = ec.valid = 0.;
+						if (e < ne) {
+							ec.n_re = ecs[e]; ec.n_im = ecs[ne + e];
+							ec.ninv2_re = ecs[2*ne + e]; ec.ninv2_im = ecs[3*ne + e];
+							ec.rough_c = ecs[4*ne + e]; ec.valid = ecs[5*ne + e];
+						}
+						while (mP) {
+							int srcv[4], myslot = -1;
+	#pragma unroll
+							for (int j = 0; j < 4; j++) {
+								srcv[j] = -1;
+								for (int k = 0; k < PP && mP; k++) {
+									const int p = __ffsll((long long)mP) - 1;
+									mP &= mP - 1ull;
+									if (sub == k) srcv[j] = p;
+									if (lane == p) myslot = 4*j + k;
+								}
+							}
+							double wv[4];
+	#pragma unroll
+							for (int j = 0; j < 4; j++) {
+								const int from = (srcv[j] < 0) ? 0 : srcv[j];
+								const int wset_p = __shfl(ph.wset, from, PC_WAVE);
+								wv[j] = (srcv[j] >= 0 && e < ne && wset_p) ? a.wscratch[(wave_gtid0 + srcv[j])*(long long)ne + e] : 1.0;
+							}
+							unsigned long long mBv[4], mKv[4];
+	#pragma unroll
+							for (int j = 0; j < 4; j++) {
+								const int from = (srcv[j] < 0) ? 0 : srcv[j];
+								pc_refl_geom gp;
+								gp.alfa = __shfl(g.alfa, from, PC_WAVE); gp.st2 = __shfl(g.st2, from, PC_WAVE);
+								gp.es2 = __shfl(g.es2, from, PC_WAVE); gp.ep2 = __shfl(g.ep2, from, PC_WAVE); gp.sd2 = __shfl(g.sd2, from, PC_WAVE);
+								int bad = 0, keep = 0;
+								if (srcv[j] >= 0 && e < ne) {
+									int r = pc_reflect_energy(ec, gp, wv[j]);
+									a.wscratch[(wave_gtid0 + srcv[j])*(long long)ne + e] = wv[j];
+									bad = (r < 0);
+									keep = (r > 0);
+								}
+								mBv[j] = __ballot(bad);
+								mKv[j] = __ballot(keep);
+							}
+							if (myslot >= 0) {
+								const int j = myslot >> 2, k = myslot & 3;
+								const unsigned long long m = gm << (k*G);
+								const unsigned long long B = (j == 0) ? mBv[0] : ((j == 1) ? mBv[1] : ((j == 2) ? mBv[2] : mBv[3]));
+								const unsigned long long K = (j == 0) ? mKv[0] : ((j == 1) ? mKv[1] : ((j == 2) ? mKv[2] : mKv[3]));
+								res = (B & m) ? -1 : ((K & m) ? 1 : 0);
+							}
+						}
+					} else
 					while (mP) {
-						int srcv[4], myslot = -1;
-#pragma unroll
-						for (int j = 0; j < 4; j++) {
-							srcv[j] = -1;
-							for (int k = 0; k < PP && mP; k++) {
-								const int p = __ffsll((long long)mP) - 1;
-								mP &= mP - 1ull;
-								if (sub == k) srcv[j] = p;
-								if (lane == p) myslot = 4*j + k;
+						const int p = __ffsll((long long)mP) - 1;
+						mP &= mP - 1ull;
+						pc_refl_geom gp;
+						gp.alfa = __shfl(g.alfa, p, PC_WAVE); gp.st2 = __shfl(g.st2, p, PC_WAVE);
+						gp.es2 = __shfl(g.es2, p, PC_WAVE); gp.ep2 = __shfl(g.ep2, p, PC_WAVE); gp.sd2 = __shfl(g.sd2, p, PC_WAVE);
+						const int wset_p = __shfl(ph.wset, p, PC_WAVE);
+						double *wp = a.wscratch + (wave_gtid0 + p)*(long long)ne;
+						int bad = 0, keep = 0;
+						for (int e0 = 0; e0 < ne; e0 += PC_WAVE*PC_KE) {
+							/* all loads of this sweep are issued before the first Fresnel evaluation */
+							double wv[PC_KE];
+	#pragma unroll
+							for (int k = 0; k < PC_KE; k++) {
+								const int e = e0 + k*PC_WAVE + lane;
+								wv[k] = (wset_p && e < ne) ? wp[e] : 1.0;
+							}
+	#pragma unroll
+							for (int k = 0; k < PC_KE; k++) {
+								const int e = e0 + k*PC_WAVE + lane;
+								if (e < ne) {
+									pc_energy_const ec;
+									ec.n_re = ecs[e]; ec.n_im = ecs[ne + e];
+									ec.ninv2_re = ecs[2*ne + e]; ec.ninv2_im = ecs[3*ne + e];
+									ec.rough_c = ecs[4*ne + e]; ec.valid = ecs[5*ne + e];
+									int r = pc_reflect_energy(ec, gp, wv[k]);
+									wp[e] = wv[k];
+									bad |= (r < 0);
+									keep |= (r > 0);
+								}
 							}
 						}
-						double wv[4];
-#pragma unroll
-						for (int j = 0; j < 4; j++) {
-							const int from = (srcv[j] < 0) ? 0 : srcv[j];
-							const int wset_p = __shfl(ph.wset, from, PC_WAVE);
-							wv[j] = (srcv[j] >= 0 && e < ne && wset_p) ? a.wscratch[(wave_gtid0 + srcv[j])*(long long)ne + e] : 1.0;
-						}
-						unsigned long long mBv[4], mKv[4];
-#pragma unroll
-						for (int j = 0; j < 4; j++) {
-							const int from = (srcv[j] < 0) ? 0 : srcv[j];
-							pc_refl_geom gp;
-							gp.alfa = __shfl(g.alfa, from, PC_WAVE); gp.st2 = __shfl(g.st2, from, PC_WAVE);
-							gp.es2 = __shfl(g.es2, from, PC_WAVE); gp.ep2 = __shfl(g.ep2, from, PC_WAVE); gp.sd2 = __shfl(g.sd2, from, PC_WAVE);
-							int bad = 0, keep = 0;
-							if (srcv[j] >= 0 && e < ne) {
-								int r = pc_reflect_energy(ec, gp, wv[j]);
-								a.wscratch[(wave_gtid0 + srcv[j])*(long long)ne + e] = wv[j];
-								bad = (r < 0);
-								keep = (r > 0);
-							}
-							mBv[j] = __ballot(bad);
-							mKv[j] = __ballot(keep);
-						}
-						if (myslot >= 0) {
-							const int j = myslot >> 2, k = myslot & 3;
-							const unsigned long long m = gm << (k*G);
-							const unsigned long long B = (j == 0) ? mBv[0] : ((j == 1) ? mBv[1] : ((j == 2) ? mBv[2] : mBv[3]));
-							const unsigned long long K = (j == 0) ? mKv[0] : ((j == 1) ? mKv[1] : ((j == 2) ? mKv[2] : mKv[3]));
-							res = (B & m) ? -1 : ((K & m) ? 1 : 0);
-						}
+						const int anybad = __any(bad), anykeep = __any(keep);
+						if (lane == p) res = anybad ? -1 : (anykeep ? 1 : 0);
 					}
-				} else
-				while (mP) {
-					const int p = __ffsll((long long)mP) - 1;
-					mP &= mP - 1ull;
-					pc_refl_geom gp;
-					gp.alfa = __shfl(g.alfa, p, PC_WAVE); gp.st2 = __shfl(g.st2, p, PC_WAVE);
-					gp.es2 = __shfl(g.es2, p, PC_WAVE); gp.ep2 = __shfl(g.ep2, p, PC_WAVE); gp.sd2 = __shfl(g.sd2, p, PC_WAVE);
-					const int wset_p = __shfl(ph.wset, p, PC_WAVE);
-					double *wp = a.wscratch + (wave_gtid0 + p)*(long long)ne;
-					int bad = 0, keep = 0;
-					for (int e0 = 0; e0 < ne; e0 += PC_WAVE*PC_KE) {
-						/* all loads of this sweep are issued before the first Fresnel evaluation */
-						double wv[PC_KE];
-#pragma unroll
-						for (int k = 0; k < PC_KE; k++) {
-							const int e = e0 + k*PC_WAVE + lane;
-							wv[k] = (wset_p && e < ne) ? wp[e] : 1.0;
-						}
-#pragma unroll
-						for (int k = 0; k < PC_KE; k++) {
-							const int e = e0 + k*PC_WAVE + lane;
-							if (e < ne) {
-								pc_energy_const ec;
-								ec.n_re = ecs[e]; ec.n_im = ecs[ne + e];
-								ec.ninv2_re = ecs[2*ne + e]; ec.ninv2_im = ecs[3*ne + e];
-								ec.rough_c = ecs[4*ne + e]; ec.valid = ecs[5*ne + e];
-								int r = pc_reflect_energy(ec, gp, wv[k]);
-								wp[e] = wv[k];
-								bad |= (r < 0);
-								keep |= (r > 0);
-							}
-						}
+				};
+				if (NE == 0 && a.lds_pend) {
+					/* the reflection waits (see flush above); the photon goes on as a survivor.  A geometry the reference rejects
+					 * (pend == 2) ends the photon with rc -1 unless a waiting reflection ends it first: both are settled
+					 * by the sweep that precedes the finalisation of every finished photon */
+					if (pend == 1) {
+						double *gq = l_pend + (size_t)threadIdx.x*(3*PC_KB) + 3*npend;
+						gq[0] = g.alfa; gq[1] = g.es2; gq[2] = g.sd2;
+						npend++;
+						res = 1;
 					}
-					const int anybad = __any(bad), anykeep = __any(keep);
-					if (lane == p) res = anybad ? -1 : (anykeep ? 1 : 0);
-				}
+				} else if (NE == 0 && a.lds_ec) sweep((const double *)(l_acc + 2*a.pm.n_energies));
+				else sweep(a.ec_soa);
 				if (pend) {
-					if (pend == 1) { ph.wset = 1; ph.ex = fabs(ph.ex); ph.ey = fabs(ph.ey); ph.ez = fabs(ph.ez); }
+					if (pend == 1) { if (!(NE == 0 && a.lds_pend)) ph.wset = 1; ph.ex = fabs(ph.ex); ph.ey = fabs(ph.ey); ph.ez = fabs(ph.ez); }
 					state = pc_event_post(Pm, ph, h, res);
+				}
+				if (NE == 0 && a.lds_pend) {
+					const unsigned long long mF = __ballot(npend == PC_KB);
+					if (mF) flush(mF);
 				}
 			}
 		} else if (nN > 0 && do_new) {
@@ -356,6 +445,10 @@ pc_trace_kernel(pc_kargs a)
 			unsigned int f_irefl = 0;
 			unsigned long long f_w = 0;
 			const long long done_slot = slot;
+			if (NE == 0 && a.lds_pend) {
+				const unsigned long long mF = __ballot(state == LS_DONE && npend > 0);
+				if (mF) flush(mF);
+			}
 			if (state == LS_DONE) {
 				const int rc = ph.rc;
 				if (EXPLICIT) {
@@ -713,6 +806,7 @@ struct pc_hip_ctx {
 	int pool_event_min = 48;
 	int pool_new_min = 48;
 	int lds_ec = 1;                /* many-energy runs: per-energy constants in LDS, one 1024-thread workgroup per CU */
+	int batch_reflections = 1;     /* more than 32 energies: sweep a photon's weights once per PC_KB reflections */
 	/* last run */
 	pc_totals *d_totals = nullptr;         /* pc_totals + 2*nE u64 */
 	size_t totals_bytes = 0;
@@ -794,7 +888,8 @@ static int pc_launch_one(pc_hip_ctx *ctx, const pc_kargs &a, int grid)
 {
 	/* table pitch: 1024 entries (48 KB of LDS) covers the reference's generated profiles (nmax = 999) and its example decks */
 	const size_t dyn = ((NE != 1 && a.lds_acc) ? 2*(size_t)ctx->host.pm.n_energies*sizeof(unsigned long long) : 0)
-	                 + ((NE == 0 && a.lds_ec) ? 6*(size_t)ctx->host.pm.n_energies*sizeof(double) : 0);
+	                 + ((NE == 0 && a.lds_ec) ? 6*(size_t)ctx->host.pm.n_energies*sizeof(double) : 0)
+	                 + ((NE == 0 && a.lds_pend) ? (size_t)(a.total_threads / grid)*3*PC_KB*sizeof(double) : 0);
 	const int block = (int)(a.total_threads / grid);
 	if (ctx->host.pm.nmax + 1 <= 1024)
 		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, 1024>), dim3(grid), dim3(block), dyn, ctx->stream, a);
@@ -832,6 +927,9 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 	/* many energies on a profile of up to 1024 points: one workgroup of 1024 threads per CU (the same 16 waves as two of
 	 * 512) leaves room in LDS for the per-energy constants next to the tables and the sums */
 	a.lds_ec = (kne == 0 && a.lds_acc && ctx->lds_ec && ctx->host.pm.nmax + 1 <= 1024 && 64*(size_t)ne <= 28672) ? 1 : 0;
+	/* more than 32 energies: PC_KB reflections per sweep of a photon's weights (their geometry waits in LDS: 96 B per lane) */
+	a.lds_pend = (a.lds_ec && ne > 32 && ctx->batch_reflections && MODE != PC_MODE_EXPLICIT) ? 1 : 0;   /* source runs only: an explicit
+	                                       * photon reports its state at the absorbing reflection, which the speculation overwrites */
 	if (pc_pool_applies<MODE>(ctx, a)) {
 		/* one 1024-thread workgroup per CU; a wave holds 64 + PQ_P photons */
 		const long long per_block = (long long)PQ_WAVES*(PC_WAVE + PQ_P);
@@ -991,6 +1089,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "block_size") { if (value < 64 || value > PC_BLOCK || (value % 64) != 0) return pc_fail(PC_HIP_ERR_INVALID, "block_size must be a multiple of 64 up to the compiled maximum"); ctx->block_size = (int)value; }
 	else if (n == "blocks_per_cu") { if (value < 1 || value > 8) return pc_fail(PC_HIP_ERR_INVALID, "blocks_per_cu must be in [1,8]"); ctx->blocks_per_cu = (int)value; }
 	else if (n == "lds_ec") ctx->lds_ec = value ? 1 : 0;
+	else if (n == "batch_reflections") ctx->batch_reflections = value ? 1 : 0;
 	else if (n == "run_parts") { if (value < 1 || value > PC_MAX_PARTS) return pc_fail(PC_HIP_ERR_INVALID, "run_parts must be in [1,16]"); ctx->run_parts = (int)value; }
 	else if (n == "fetch_threads") { if (value < 0 || value > 256) return pc_fail(PC_HIP_ERR_INVALID, "fetch_threads must be in [0,256]"); ctx->fetch_threads = (int)value; }
 	else if (n == "pool") ctx->pool = value ? 1 : 0;

@@ -2,11 +2,14 @@
 kernels and is compared with the CPU oracle on identical inputs.
 
 Tolerances.  The reference's trace is chaotic: a 1-ulp change of a start coordinate grows by ~5-8x per
-reflection (tests/test_chaos_floor.py measures it on the oracle itself), so two correct fp64 implementations
+reflection (tests/test_chaos_floor.py measures it on the oracle itself, profiles/r02/parity_1e8.json shows the
+device's differences growing at the same rate from a ten times smaller start), so two correct fp64 implementations
 agree per photon only while few reflections have happened, and agree statistically afterwards.  Hence:
   * single-event / short trajectories: tight absolute tolerances that grow with the reflection count;
-  * discrete outcomes and efficiencies on identical seeds: equal within the reference's own 1-ulp self-noise
-    (tolerance c/sqrt(N) with c stated in each test);
+  * discrete outcomes and efficiencies on identical seeds: equal within c/sqrt(N); measured c = 0.48 for the
+    efficiency at 10 keV (128 seeds x 1e6 slots, no bias), the tests allow 1.0 (more where many energies or
+    rarely-hit high energies widen the spread, stated in each test); at N = 2.4e8 started photons the delta is
+    1.4e-5, inside the north-star 1e-4 (tests/test_parity_fixture.py);
   * GPU vs the host compile of the same device header: bit-identical (both are the same IEEE operation sequence).
 """
 import numpy as np
@@ -147,9 +150,10 @@ def test_transmission_driver_vs_oracle(pa, oracle, known):
     # the reference's published known answer (tests/source.c:218): 0.135 +- 0.0075 at 10 keV
     assert abs(g["efficiencies"][0] - 0.135) <= 0.0075
     # same seed, same slots.  Photons whose trajectories decorrelate (chaos) also change the retry sequence of their
-    # slot, so i_start (sum of ~geometric attempt counts, variance ~4 per slot) and the efficiency differ by
-    # ~1/sqrt(i_start) (1 sigma); tolerance 4/sqrt(i_start)
-    tol = 4.0 / np.sqrt(g["i_start"])
+    # slot, so i_start and the efficiency differ by c/sqrt(i_start) with c = 0.48 measured over 128 seeds x 1e6 slots
+    # (profiles/r02/parity_1e8.json: no bias, mean delta -1.4e-5 +- 3.1e-5); tolerance 2 x that spread (the run is
+    # reproducible bit for bit, so the assertion is deterministic)
+    tol = 1.0 / np.sqrt(g["i_start"])
     assert abs(g["i_start"] - o["i_start"]) / o["i_start"] < tol
     assert abs(g["efficiencies"][0] - o["efficiencies"][0]) / o["efficiencies"][0] < tol
     assert abs(g["sum_irefl"] - o["sum_irefl"]) / o["sum_irefl"] < tol
@@ -227,7 +231,7 @@ def test_multi_energy_and_roughness(pa, oracle):
     flips = ((o["rc"] != g["rc"]) | (o["i_refl"] != g["i_refl"])).mean()
     assert flips < 0.10
     so, sg = o["weights"][o["rc"] == 1].sum(axis=0), g["weights"][g["rc"] == 1].sum(axis=0)
-    assert np.all(np.abs(sg - so) / so < 3.0 / np.sqrt(n))
+    assert np.all(np.abs(sg - so) / so < 1.5 / np.sqrt(n))      # the weight spread grows with energy: 1.5 instead of 1.0
     short = (o["rc"] == g["rc"]) & (o["i_refl"] == g["i_refl"]) & (o["i_refl"] <= 3) & np.isin(o["rc"], (0, 1))
     assert rel(g["weights"][short], o["weights"][short]).max() < 1e-6
     assert np.all(np.diff(t["efficiencies"]) < 0)      # transmission falls with energy
@@ -412,7 +416,7 @@ def test_long_profile_uses_the_wide_lds_tables(pa, oracle):
             assert np.array_equal(g[k], e[k], equal_nan=True), (energies, k)
         o = oracle.transmission(optic, oracle.make_source(*source), E, amu, scatf, 5, 0, 50000)
         assert t["i_exit"] == 50000
-        assert np.all(np.abs(t["efficiencies"] - o["efficiencies"]) <= 4. / np.sqrt(o["i_start"]) * o["efficiencies"] + 1e-12)
+        assert np.all(np.abs(t["efficiencies"] - o["efficiencies"]) <= 2. / np.sqrt(o["i_start"]) * o["efficiencies"] + 1e-12)
 
 
 @pytest.mark.parametrize("n_energies", [12, 24, 40, 291])
@@ -431,7 +435,7 @@ def test_many_energies_match_the_host_compile(pa, oracle, n_energies):
         assert np.array_equal(g[k], e[k], equal_nan=True), k
     o = oracle.transmission(optic, src, E, A, S, 9, 0, 20000)
     assert t["i_exit"] == 20000
-    assert np.all(np.abs(t["efficiencies"] - o["efficiencies"]) <= 4. / np.sqrt(o["i_start"]) * o["efficiencies"] + 1e-12)
+    assert np.all(np.abs(t["efficiencies"] - o["efficiencies"]) <= 2.5 / np.sqrt(o["i_start"]) * o["efficiencies"] + 1e-12)
     w = t["exit_weights"]
     assert w.shape == (20000, n_energies) and np.all((w >= 0) & (w <= 1)) and np.all(w.max(axis=1) >= 1e-4)
     # checksum of checksums: the per-slot weights add up to the exact fixed-point totals, energy by energy
