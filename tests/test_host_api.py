@@ -168,8 +168,22 @@ def test_optical_constants_pin(known):
     assert not synthetic
     amu, scatf, synthetic = polycap_amd.optical_constants(g["iz"], g["wi_percent"], g["density"], [1., 1.8, 1.9, 5., 30., 100.])
     assert synthetic and np.all(amu > 0) and np.all(scatf > 0.3) and amu[2] > amu[1]    # Si K edge between 1.8 and 1.9 keV
-    with pytest.raises(ValueError, match="no optical constants for Z=82"):
-        polycap_amd.optical_constants([82], [1.0], 11.3, [10.0])
+    # elements of common capillary glasses come from the built-in tables, always flagged synthetic (unverified offline);
+    # anything else needs xraylib
+    with pytest.raises(ValueError, match="no optical constants for Z=26"):
+        polycap_amd.optical_constants([26], [1.0], 7.9, [10.0])
+    boro = ([5, 8, 11, 13, 14, 19], [4.0, 53.9, 2.8, 1.1, 37.7, 0.5], 2.23)      # borosilicate glass
+    amu, scatf, synthetic = polycap_amd.optical_constants(*boro, [3.0, 3.7, 10.0, 30.0])
+    assert synthetic and np.all(np.diff(amu[[0, 2, 3]]) < 0) and np.all((scatf > 0.45) & (scatf < 0.52))
+    lead = ([8, 14, 19, 82], [30., 25., 5., 40.], 4.0)                          # lead glass: L edges at 13.0, 15.2 and 15.9 keV
+    amu, scatf, synthetic = polycap_amd.optical_constants(*lead, [12.9, 13.2, 15.1, 16.0, 87.0, 89.0])
+    assert synthetic and amu[1] > 1.5 * amu[0] and amu[3] > amu[2] and amu[5] > 2 * amu[4]
+    # Z / A of the compound minus the anomalous part: scatf stays a little below sum(w Z / A)
+    zoa = sum(w / 100. * z / a for z, w, a in zip(lead[0], lead[1], (15.9994, 28.0855, 39.0983, 207.2)))
+    assert np.all(scatf < zoa) and np.all(scatf > 0.9 * zoa)
+    # the pinned 10 keV pair of the reference glass is untouched by the other tables
+    amu, scatf, synthetic = polycap_amd.optical_constants(g["iz"], g["wi_percent"], g["density"], [10.0])
+    assert abs(amu[0] - g["amu"]) < g["amu_tol"] and not synthetic
     with pytest.raises(ValueError, match="energies"):
         polycap_amd.optical_constants(g["iz"], g["wi_percent"], g["density"], [0.5])
 
