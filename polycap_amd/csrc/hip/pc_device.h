@@ -57,6 +57,7 @@ struct pc_params {
 	double hexscale;    /* 2*cos(pi/6)*(n_shells+1) */
 	double adj;         /* certificate margin: see pc_march_ok */
 	double two_rmax;    /* 2 * max_i cap[i] (block certificates) */
+	float adjf, two_rmaxf;  /* the same two, rounded up to float and inflated by PC_MARGIN_INFLATE: pc_march_ok decides in float */
 	double bnd_thresh;  /* max_i cap[i]/ext[i] (+slack): capillaries closer than this to the hexagon edge are "boundary" */
 	double z_end, ext_end;
 	double d_source, src_x, src_y, src_sigx, src_sigy, src_shiftx, src_shifty, frac_hor_pol;
@@ -87,6 +88,7 @@ struct pc_tables {
 #ifndef PC_L2
 #define PC_L2 25
 #endif
+#define PC_MARGIN_INFLATE 1.0000038f   /* 1 + 2^-18 */
 #ifndef PC_LV_LATER
 #define PC_LV_LATER 2  /* widest level a flight after a reflection starts with */
 #endif
@@ -442,15 +444,21 @@ PC_HD int pc_march_ok(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph
 	const int cap = ph.lv;
 	const int i0 = ph.i;
 	int lv = 0;
-	double marg = Pm.adj;
+	/* The certificate VALUES are fp64 (they decide nothing by themselves: a node that is not certified is visited
+	 * literally); the comparison against the margins is made in single precision with every margin inflated by
+	 * PC_MARGIN_INFLATE (2^-18, far above the three float roundings involved), so that "Cf < -mf" implies C < -m for the
+	 * exact values.  Margins of both strides are then 3 float operations each instead of 2 conversions + 3 fp64 operations. */
+	float marg = Pm.adjf;
+	const float C0f = (float)ph.C0;
 	{
 		/* a stride that does not fit before the end of the profile has an infinite margin: no index test needed */
 		const pc_marg4 g = T.mg[i0];
-		const double kd1 = ph.kn * (double)g.md1, kd2 = ph.kn * (double)g.md2;
-		const double m1 = fma(kd1, Pm.two_rmax + kd1, (double)g.mb1);
-		const double m2 = fma(kd2, Pm.two_rmax + kd2, (double)g.mb2);
-		if (cap >= 1 && ph.C0 < -m1) { lv = 1; marg = m1; }
-		if (cap >= 2 && ph.C0 < -m2) { lv = 2; marg = m2; }
+		const float knf = (float)ph.kn * PC_MARGIN_INFLATE;
+		const float kd1 = knf * g.md1, kd2 = knf * g.md2;
+		const float m1 = fmaf(kd1, Pm.two_rmaxf + kd1, g.mb1 * PC_MARGIN_INFLATE);
+		const float m2 = fmaf(kd2, Pm.two_rmaxf + kd2, g.mb2 * PC_MARGIN_INFLATE);
+		if (cap >= 1 && C0f < -m1) { lv = 1; marg = m1; }
+		if (cap >= 2 && C0f < -m2) { lv = 2; marg = m2; }
 	}
 	const int L = (lv == 0) ? 1 : ((lv == 1) ? PC_L1 : PC_L2);
 	const int i1 = i0 + L;
@@ -458,7 +466,7 @@ PC_HD int pc_march_ok(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph
 	double qx = fma(-ph.kx, zh1, fma(ph.sx, z1, ph.ox));
 	double qy = fma(-ph.ky, zh1, fma(ph.sy, z1, ph.oy));
 	double C1 = fma(qx, qx, fma(qy, qy, -c2));
-	int ok = (ph.C0 < -marg) & (C1 < -marg);
+	int ok = (C0f < -marg) & ((float)C1 < -marg);
 	if (ph.bnd) {
 		/* boundary capillary (or mono-capillary; always level 0): the hexagon tests of the visit are not implied, do them:
 		 * axis at both nodes (src/polycap-capil.c:1263) and the ray at z_i (:1296-1308) */

@@ -1163,7 +1163,7 @@ static int pc_launch_photons_impl(pc_hip_ctx *ctx, int64_t n, const double *star
 		a.out_irefl = d_ir; a.out_dtravel = d_dt;
 		if (leak) {
 			/* polycap_photon_launch(..., leak_calc=true): rerun with a larger record buffer until every event fits */
-			long long capacity = ctx->leak_capacity > 0 ? ctx->leak_capacity : std::max<long long>(4096, 16*n);
+			long long capacity = ctx->leak_capacity > 0 ? ctx->leak_capacity : std::max<long long>(4096, (16 + 8*(long long)ne)*n);
 			ctx->leak_slot0 = 0;
 			for (;;) {
 				ctx->leak_capacity_used = capacity;
@@ -1362,7 +1362,10 @@ int pc_hip_transmission_run_leak(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, 
 	ctx->n_parts = 1;
 	ctx->leak_seed = seed; ctx->leak_slot0 = slot0; ctx->leak_n_slots = n_slots;
 	ctx->leak_max_attempts = max_attempts; ctx->leak_keep_images = keep_images ? 1 : 0;
-	ctx->leak_capacity_used = ctx->leak_capacity > 0 ? ctx->leak_capacity : std::max<long long>(65536, 16*n_slots);
+	/* record buffer: events per slot grow with the number of energies (a leak is kept while ANY energy holds >= 1e-4):
+	 * 9 per slot at one energy, 29 at seven on the reference's test optic; a run that outgrows the buffer is repeated, so
+	 * the first guess is generous (16 + 8 n_energies records per slot) */
+	ctx->leak_capacity_used = ctx->leak_capacity > 0 ? ctx->leak_capacity : std::max<long long>(65536, (16 + 8*(long long)ne)*n_slots);
 	int status = pc_transmission_enqueue_leak(ctx);
 	if (status) return status;
 	ctx->run_slots = n_slots;

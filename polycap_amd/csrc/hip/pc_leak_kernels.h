@@ -15,7 +15,6 @@
 #define PC_LEAK_KERNELS_H
 
 #include <algorithm>
-#include <unordered_set>
 
 #define PC_LEAK_BLOCK 256
 
@@ -352,39 +351,74 @@ static int pc_leak_collect(pc_hip_ctx *ctx, long long n_slots, bool explicit_mod
 		final_attempt.resize((size_t)n_slots);
 		PC_HIP_CHECK(hipMemcpy(final_attempt.data(), ctx->d_leak_attempts, (size_t)n_slots*sizeof(unsigned int), hipMemcpyDeviceToHost));
 	}
-	struct key_hash { size_t operator()(const std::pair<long long, long long> &k) const { return std::hash<long long>()(k.first*1000003ll + k.second); } };
-	std::unordered_set<std::pair<long long, long long>, key_hash> voided;
-	for (size_t k = 0; k < n; k++) {
-		const double *r = recs.data() + k*stride;
-		if (r[PC_LR_KIND] < 0.) voided.insert({(long long)r[PC_LR_SLOT], (long long)r[PC_LR_ATTEMPT]});
-	}
-	struct item { long long slot, order, seq; size_t idx; };
-	std::vector<item> items;
-	items.reserve(n);
+	/* Ordering in O(n): records are bucketed by slot (counting sort), every bucket -- a few dozen events -- is put into
+	 * (transmitted attempt first, attempt, seq) order on its own, attempts that appended a VOID record are dropped; host
+	 * threads share the slot range and their pieces are concatenated in slot order.  (A comparison sort of all records
+	 * took 6 s for 7.6 M events.) */
 	const long long slot0 = ctx->leak_slot0;
+	const size_t ns = (size_t)n_slots;
+	std::vector<unsigned int> first(ns + 1, 0);
 	for (size_t k = 0; k < n; k++) {
-		const double *r = recs.data() + k*stride;
-		if (r[PC_LR_KIND] < 0.) continue;
-		const long long slot = (long long)r[PC_LR_SLOT], att = (long long)r[PC_LR_ATTEMPT];
-		if (!voided.empty() && voided.count({slot, att})) continue;
-		long long order = att + 1;
-		if (!explicit_mode && (long long)final_attempt[(size_t)(slot - slot0)] == att) order = 0;   /* the transmitted photon's own events come first */
-		items.push_back({slot, order, (long long)r[PC_LR_SEQ], k});
+		const long long sl = (long long)recs[k*stride + PC_LR_SLOT] - slot0;
+		if (sl < 0 || sl >= n_slots) return pc_fail(PC_HIP_ERR_RUNTIME, "leak run: event record with a slot outside the run");
+		first[(size_t)sl + 1]++;
 	}
-	std::sort(items.begin(), items.end(), [](const item &x, const item &y) {
-		if (x.slot != y.slot) return x.slot < y.slot;
-		if (x.order != y.order) return x.order < y.order;
-		return x.seq < y.seq; });
+	for (size_t j = 0; j < ns; j++) first[j + 1] += first[j];
+	std::vector<unsigned int> bucket(n), fill(first.begin(), first.end() - 1);
+	for (size_t k = 0; k < n; k++)
+		bucket[fill[(size_t)((long long)recs[k*stride + PC_LR_SLOT] - slot0)]++] = (unsigned int)k;
 	const size_t ostride = PC_HIP_LEAK_HDR + ne;
-	for (const item &it : items) {
-		const double *r = recs.data() + it.idx*stride;
-		std::vector<double> &dst = (r[PC_LR_KIND] == (double)PC_LEAK_EXT) ? ctx->leak_ext : ctx->leak_int;
-		const size_t at = dst.size();
-		dst.resize(at + ostride);
-		double *o = dst.data() + at;
-		o[0] = r[PC_LR_SLOT]; o[1] = r[PC_LR_ATTEMPT];
-		for (int c = 0; c < 10; c++) o[2 + c] = r[PC_LR_X + c];      /* coords, direction, elecv, n_refl */
-		for (size_t e = 0; e < ne; e++) o[PC_HIP_LEAK_HDR + e] = r[PC_LR_WEIGHTS + e];
+	unsigned hw = std::thread::hardware_concurrency();
+	const size_t nthreads = (n < 200000) ? 1 : (hw == 0 ? 4 : (hw > 16 ? 16 : hw));
+	std::vector<std::vector<double>> out_ext(nthreads), out_int(nthreads);
+	auto work = [&](size_t t) {
+		const size_t j0 = ns*t/nthreads, j1 = ns*(t + 1)/nthreads;
+		struct item { long long order, seq; unsigned int idx; };
+		std::vector<item> items;
+		std::vector<long long> voided;
+		for (size_t j = j0; j < j1; j++) {
+			items.clear(); voided.clear();
+			for (unsigned int q = first[j]; q < first[j + 1]; q++) {
+				const double *r = recs.data() + (size_t)bucket[q]*stride;
+				if (r[PC_LR_KIND] < 0.) voided.push_back((long long)r[PC_LR_ATTEMPT]);
+			}
+			for (unsigned int q = first[j]; q < first[j + 1]; q++) {
+				const double *r = recs.data() + (size_t)bucket[q]*stride;
+				if (r[PC_LR_KIND] < 0.) continue;
+				const long long att = (long long)r[PC_LR_ATTEMPT];
+				if (!voided.empty() && std::find(voided.begin(), voided.end(), att) != voided.end()) continue;
+				long long order = att + 1;
+				if (!explicit_mode && (long long)final_attempt[j] == att) order = 0;   /* the transmitted photon's own events come first */
+				items.push_back({order, (long long)r[PC_LR_SEQ], bucket[q]});
+			}
+			std::sort(items.begin(), items.end(), [](const item &x, const item &y) {
+				if (x.order != y.order) return x.order < y.order;
+				return x.seq < y.seq; });
+			for (const item &it : items) {
+				const double *r = recs.data() + (size_t)it.idx*stride;
+				std::vector<double> &dst = (r[PC_LR_KIND] == (double)PC_LEAK_EXT) ? out_ext[t] : out_int[t];
+				const size_t at = dst.size();
+				dst.resize(at + ostride);
+				double *o = dst.data() + at;
+				o[0] = r[PC_LR_SLOT]; o[1] = r[PC_LR_ATTEMPT];
+				for (int c = 0; c < 10; c++) o[2 + c] = r[PC_LR_X + c];      /* coords, direction, elecv, n_refl */
+				for (size_t e = 0; e < ne; e++) o[PC_HIP_LEAK_HDR + e] = r[PC_LR_WEIGHTS + e];
+			}
+		}
+	};
+	{
+		std::vector<std::thread> th;
+		for (size_t t = 1; t < nthreads; t++) th.emplace_back(work, t);
+		work(0);
+		for (auto &x : th) x.join();
+	}
+	size_t tot_ext = 0, tot_int = 0;
+	for (size_t t = 0; t < nthreads; t++) { tot_ext += out_ext[t].size(); tot_int += out_int[t].size(); }
+	ctx->leak_ext.reserve(tot_ext); ctx->leak_int.reserve(tot_int);
+	for (size_t t = 0; t < nthreads; t++) {
+		ctx->leak_ext.insert(ctx->leak_ext.end(), out_ext[t].begin(), out_ext[t].end());
+		ctx->leak_int.insert(ctx->leak_int.end(), out_int[t].begin(), out_int[t].end());
+		std::vector<double>().swap(out_ext[t]); std::vector<double>().swap(out_int[t]);
 	}
 	ctx->leak_n_ext = (long long)(ctx->leak_ext.size() / ostride);
 	ctx->leak_n_int = (long long)(ctx->leak_int.size() / ostride);

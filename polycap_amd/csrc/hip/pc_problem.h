@@ -89,6 +89,9 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 	double m = std::fmax(1e-6*capmin*capmin, 1e-10*capmax*extmax);
 	pm.adj = 0.25*dr2max + m;
 	pm.two_rmax = 2.*capmax;
+	/* float copies for the comparisons of pc_march_ok: rounded up, then inflated */
+	pm.adjf = std::nextafter((float)pm.adj, HUGE_VALF) * PC_MARGIN_INFLATE;
+	pm.two_rmaxf = std::nextafter((float)pm.two_rmax, HUGE_VALF) * PC_MARGIN_INFLATE;
 	/* block certificates: for every start node the chord deviations over the next L segments */
 	for (int lvl = 1; lvl <= 2; lvl++) {
 		const int L = (lvl == 1) ? PC_L1 : PC_L2;
