@@ -96,7 +96,8 @@ def main():
     dev_index = local_rank if args.backend == "nccl" else local_rank % polycap_amd.device_count()
     torch = dist = None
     red_dev = None
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ      # torch.distributed.run, any world size
+    if world > 1 or under_launcher:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -119,12 +120,13 @@ def main():
     slot0 = rank * n_local           # weak scaling: rank r owns slots [r*n, (r+1)*n)
 
     def barrier():
-        # the trace runs on the library's own stream and step() returns only after pc_hip_transmission_wait has
-        # synchronised it, so the device is idle here; with ranks, the process-group barrier lines them up
-        if world > 1:
+        # with ranks (any job under torch.distributed.run) the process-group barrier lines them up; then the whole device
+        # is synchronised: torch's streams through torch.cuda.synchronize, the library's own through hipDeviceSynchronize
+        if dist is not None:
             dist.barrier()
             if red_dev is not None:
                 torch.cuda.synchronize()
+        ctx.device_synchronize()
 
     def step(k):
         ctx.run(args.seed + k, slot0, n_local, keep_images=keep_images)
@@ -149,7 +151,7 @@ def main():
         last = (counters, sums)
     barrier()
     wall = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([wall], dtype=torch.float64, device=red_dev if red_dev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
@@ -217,7 +219,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(prob, args, ctx)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -50,7 +50,7 @@ def allreduce_totals(vec, device=None):
         return np.asarray(vec, dtype=np.int64)      # single process: do not even import torch
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return np.asarray(vec, dtype=np.int64)
     t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.int64))
     if device is not None:

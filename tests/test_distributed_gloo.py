@@ -103,3 +103,64 @@ def test_two_rank_gloo_equals_single_rank():
         assert eff == single["efficiencies"].tolist()
     assert [r[4] for r in res] == [0, 301] and [r[5] for r in res] == [301, 300]
     assert single["counters"][0] == n_total
+
+
+def _gpu_worker(rank, world, port, n_total, seed, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from polycap_amd import distributed as pcd
+    from tests.common import make_pair
+    from oracle import pyoracle as O
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        _, _, prob, _ = make_pair(O, "xos1", source=(2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.0))
+        r = pcd.run_sharded(prob, seed, n_total, rank=rank, world_size=world, device_index=0)     # the HIP kernel
+        out_q.put((rank, r["counters"].tolist(), [str(v) for v in r["sumw_exact"]], r["efficiencies"].tolist(), r["slot0"], r["n_local"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_the_hip_kernel_equal_one_rank():
+    """The N > 1 path with the real kernel: two processes (gloo; they share the box's one GPU) trace their slot shares
+    with the HIP kernel and all-reduce the packed totals; the result equals the single-rank run bit for bit."""
+    import torch.multiprocessing as mp
+    from polycap_amd import distributed as pcd
+    from tests.common import make_pair
+    from oracle import pyoracle as O
+    n_total, seed = 400_001, 31
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, n_total, seed, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    _, _, prob, _ = make_pair(O, "xos1", source=(2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.0))
+    single = pcd.run_sharded(prob, seed, n_total, device_index=0)
+    for rank, counters, exact, eff, slot0, n_local in res:
+        assert counters[:4] == single["counters"][:4].tolist()
+        assert exact == [str(v) for v in single["sumw_exact"]]
+        assert eff == single["efficiencies"].tolist()
+    assert [r[4] for r in res] == [0, 200_001] and [r[5] for r in res] == [200_001, 200_000]
+
+
+@pytest.mark.gpu
+def test_bench_under_the_launcher_with_rccl_world_of_one():
+    """bench.py exactly as the driver starts it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), with the
+    one rank a one-GPU box allows: process group on RCCL, the all-reduce of the packed totals on the device, the barrier."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--photons", "300000", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 1e7 and d["roofline"]["kernel_ms"] > 0
