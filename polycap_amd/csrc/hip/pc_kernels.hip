@@ -20,6 +20,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -87,7 +88,12 @@ struct pc_kargs {
 	pc_totals *totals;
 	unsigned long long *work;     /* the launch's work counter (relative slot index handed out next) */
 	unsigned long long *sumw;     /* 2*n_energies */
-	double *img;                  /* [n_slots][17 + n_energies] records, or NULL */
+	double *img;                  /* image store of the launch's slots, or NULL: field f of slot j at img[j*img_ss + f*img_fs], weight e at
+	                               * img_w[j*img_ws + e].  Records (one per slot): img_ss = 17 + n_energies, img_fs = 1, img_w = img + 17,
+	                               * img_ws = img_ss.  Planes (struct _polycap_images): img_ss = 1, img_fs = slots of the run, img_w = weights
+	                               * [slot][n_energies], img_ws = n_energies */
+	double *img_w;
+	long long img_ss, img_fs, img_ws;
 	int new_threshold;
 	int lds_acc;                  /* NE == 0: accumulate weight sums in LDS (2*n_energies u64 of dynamic LDS) */
 	int lds_ec;                   /* NE == 0: per-energy constants staged in LDS behind the sums (6*n_energies doubles) */
@@ -163,7 +169,7 @@ pc_trace_kernel(pc_kargs a)
 	pc_tables T;
 	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.hexd = l_hexd; T.idz = l_idz; T.ext = a.g_ext;
 	T.mg = ldsg;
-	const long long rec = PC_N_FIELDS + (long long)a.pm.n_energies;   /* doubles per image record */
+	const long long fs = a.img_fs, ss = a.img_ss, ws = a.img_ws;      /* strides of the image store: records or planes (pc_kargs) */
 	const pc_params &Pm = a.pm;
 	const int ne = (NE > 0) ? NE : Pm.n_energies;
 	const int ner = Pm.n_energies;   /* NE > 1 serves any n_energies <= NE: the surplus weights start at 0 and stay there */
@@ -478,7 +484,7 @@ pc_trace_kernel(pc_kargs a)
 						if (NE == 1) {
 							double w = ph.w[0];
 							f_w = (unsigned long long)(w * PC_FIX_SCALE);
-							if (a.keep_images) a.img[slot*rec + PC_F_WEIGHTS] = w;
+							if (a.keep_images) a.img_w[slot*ws] = w;
 						} else if (NE > 1) {
 							/* a few energies: exact sums in LDS (2 x u64 per energy), flushed once per workgroup */
 #pragma unroll
@@ -488,7 +494,7 @@ pc_trace_kernel(pc_kargs a)
 									unsigned long long f = (unsigned long long)(w * PC_FIX_SCALE);
 									unsigned long long old = atomicAdd(&l_acc[2*e], f);
 									if (old + f < old) atomicAdd(&l_acc[2*e + 1], 1ull);
-									if (a.keep_images) a.img[slot*rec + PC_F_WEIGHTS + e] = w;
+									if (a.keep_images) a.img_w[slot*ws + e] = w;
 								}
 							}
 						} else {
@@ -496,18 +502,18 @@ pc_trace_kernel(pc_kargs a)
 						}
 						if (a.keep_images) {
 							/* src/polycap-source.c:900-923 */
-							double *r = a.img + slot*rec;
+							double *r = a.img + slot*ss;
 							double t = (Pm.z_end - ph.Pz) / ph.dz;
 							double ex = ph.Px + ph.dx*t, ey = ph.Py + ph.dy*t, ez = ph.Pz + ph.dz*t;
-							r[PC_F_EXITX] = ex; r[PC_F_EXITY] = ey; r[PC_F_EXITZ] = ez;
-							r[PC_F_EDIRX] = ph.dx; r[PC_F_EDIRY] = ph.dy;
+							r[PC_F_EXITX*fs] = ex; r[PC_F_EXITY*fs] = ey; r[PC_F_EXITZ*fs] = ez;
+							r[PC_F_EDIRX*fs] = ph.dx; r[PC_F_EDIRY*fs] = ph.dy;
 							const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
 							double tx = ph.ex*c_ae + ph.dx*c_be, ty = ph.ey*c_ae + ph.dy*c_be, tz = ph.ez*c_ae + ph.dz*c_be;
 							pc_norm3(tx, ty, tz);
-							r[PC_F_EEVX] = round(tx); r[PC_F_EEVY] = round(ty);
-							((long long *)r)[PC_F_NREFL] = ph.irefl;
+							r[PC_F_EEVX*fs] = round(tx); r[PC_F_EEVY*fs] = round(ty);
+							((long long *)r)[PC_F_NREFL*fs] = ph.irefl;
 							double lx = ex - ph.Px, ly = ey - ph.Py, lz = Pm.z_end - ph.Pz;
-							r[PC_F_DTRAVEL] = ph.dtravel + sqrt(lx*lx + ly*ly + lz*lz);
+							r[PC_F_DTRAVEL*fs] = ph.dtravel + sqrt(lx*lx + ly*ly + lz*lz);
 						}
 						state = LS_NEED_SLOT;
 					} else {
@@ -515,7 +521,7 @@ pc_trace_kernel(pc_kargs a)
 						if (attempt >= a.max_attempts) {
 							f_failed = 1;
 							if (a.keep_images) {
-								if (NE > 0) for (int e = 0; e < ner; e++) a.img[slot*rec + PC_F_WEIGHTS + e] = 0.;
+								if (NE > 0) for (int e = 0; e < ner; e++) a.img_w[slot*ws + e] = 0.;
 								else coop = 2;   /* zero weights */
 							}
 							state = LS_NEED_SLOT;
@@ -550,7 +556,7 @@ pc_trace_kernel(pc_kargs a)
 									pc_atomic_add128(a.sumw + 2*e, f, 0ull);
 								}
 							}
-							if (a.keep_images) a.img[slot_p*rec + PC_F_WEIGHTS + e] = w;
+							if (a.keep_images) a.img_w[slot_p*ws + e] = w;
 						}
 					}
 				}
@@ -609,13 +615,13 @@ pc_trace_kernel(pc_kargs a)
 						cosalpha0 = s.ex*s.dx + s.ey*s.dy + s.ez*s.dz;
 						if (a.keep_images) {
 							const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
-							double *r = a.img + slot*rec;
-							r[PC_F_SRCX] = s.srcx; r[PC_F_SRCY] = s.srcy;
-							r[PC_F_STARTX] = s.x; r[PC_F_STARTY] = s.y;
-							r[PC_F_SDIRX] = s.dx; r[PC_F_SDIRY] = s.dy;
+							double *r = a.img + slot*ss;
+							r[PC_F_SRCX*fs] = s.srcx; r[PC_F_SRCY*fs] = s.srcy;
+							r[PC_F_STARTX*fs] = s.x; r[PC_F_STARTY*fs] = s.y;
+							r[PC_F_SDIRX*fs] = s.dx; r[PC_F_SDIRY*fs] = s.dy;
 							double tx = s.ex*c_ae + s.dx*c_be, ty = s.ey*c_ae + s.dy*c_be, tz = s.ez*c_ae + s.dz*c_be;
 							pc_norm3(tx, ty, tz);
-							r[PC_F_SEVX] = round(tx); r[PC_F_SEVY] = round(ty);
+							r[PC_F_SEVX*fs] = round(tx); r[PC_F_SEVY*fs] = round(ty);
 						}
 					}
 				}
@@ -667,6 +673,32 @@ pc_trace_kernel(pc_kargs a)
 }
 
 #include "pc_pool_kernel.h"
+
+/* Image records (one contiguous record of 17 + n_energies doubles per slot) -> the planes of struct _polycap_images: 17
+ * planes of n_total doubles each, then the weights as [slot][n_energies].  A workgroup stages PC_SOA_TILE records in LDS
+ * with coalesced reads and writes every plane with coalesced stores: 2 x 144 B of HBM traffic per photon, about a
+ * millisecond per 1e7 photons, instead of a strided gather by host threads behind PCIe. */
+#define PC_SOA_TILE 128
+__global__ void __launch_bounds__(256) pc_soa_kernel(const double *rec, double *soa, long long first, long long count, long long n_total, int ne)
+{
+	extern __shared__ double tile[];
+	const int recd = PC_N_FIELDS + ne;
+	const long long j0 = first + (long long)blockIdx.x*PC_SOA_TILE;
+	const int m = (int)((first + count - j0 < PC_SOA_TILE) ? first + count - j0 : PC_SOA_TILE);
+	if (m <= 0) return;
+	const double *src = rec + j0*recd;
+	for (int k = threadIdx.x; k < m*recd; k += blockDim.x) tile[k] = src[k];
+	__syncthreads();
+	for (int k = threadIdx.x; k < m*PC_N_FIELDS; k += blockDim.x) {
+		const int plane = k / m, t = k - plane*m;
+		soa[(long long)plane*n_total + j0 + t] = tile[t*recd + plane];
+	}
+	double *w = soa + (long long)PC_N_FIELDS*n_total + j0*ne;
+	for (int k = threadIdx.x; k < m*ne; k += blockDim.x) {
+		const int t = k / ne, e = k - t*ne;
+		w[k] = tile[t*recd + PC_N_FIELDS + e];
+	}
+}
 
 /* source sampling only (parity of polycap_source_get_photon) */
 __global__ void pc_sample_kernel(pc_params pm, unsigned long long seed, long long n,
@@ -829,6 +861,12 @@ struct pc_hip_ctx {
 	int fetch_threads = 0;                 /* host threads that scatter a fetched chunk into the caller's planes; 0 = min(16, cores) */
 	long long img_slots = 0;
 	int img_valid = 0;
+	/* plane (SoA) copy of the image records on the device: 17 planes of soa_slots doubles, then the weights [slot][n_energies].
+	 * pc_hip_transmission_images copies from here straight into the caller's (registered) planes -- no host transposition */
+	double *d_soa = nullptr;
+	long long soa_slots = 0;
+	int plane_images = 0;                  /* option "plane_images": runs that keep images write the planes themselves (no records) */
+	int run_planes = 0;                    /* the last run did so */
 	double *d_wscratch = nullptr;
 	size_t wscratch_elems = 0;
 	/* explicit-photon calls (polycap_photon_launch, polycap_source_get_photon): one device buffer and one pinned host
@@ -1000,6 +1038,7 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->d_ftables) (void)hipFree(ctx->d_ftables);
 	if (ctx->d_totals) (void)hipFree(ctx->d_totals);
 	if (ctx->d_img) (void)hipFree(ctx->d_img);
+	if (ctx->d_soa) (void)hipFree(ctx->d_soa);
 	if (ctx->h_stage) { if (ctx->h_stage_pinned) (void)hipHostFree(ctx->h_stage); else free(ctx->h_stage); }
 	for (int k = 0; k < 2; k++) if (ctx->ev_fetch[k]) (void)hipEventDestroy(ctx->ev_fetch[k]);
 	for (int k = 0; k < PC_MAX_PARTS; k++) if (ctx->ev_part[k]) (void)hipEventDestroy(ctx->ev_part[k]);
@@ -1090,6 +1129,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "blocks_per_cu") { if (value < 1 || value > 8) return pc_fail(PC_HIP_ERR_INVALID, "blocks_per_cu must be in [1,8]"); ctx->blocks_per_cu = (int)value; }
 	else if (n == "lds_ec") ctx->lds_ec = value ? 1 : 0;
 	else if (n == "batch_reflections") ctx->batch_reflections = value ? 1 : 0;
+	else if (n == "plane_images") ctx->plane_images = value ? 1 : 0;
 	else if (n == "run_parts") { if (value < 1 || value > PC_MAX_PARTS) return pc_fail(PC_HIP_ERR_INVALID, "run_parts must be in [1,16]"); ctx->run_parts = (int)value; }
 	else if (n == "fetch_threads") { if (value < 0 || value > 256) return pc_fail(PC_HIP_ERR_INVALID, "fetch_threads must be in [0,256]"); ctx->fetch_threads = (int)value; }
 	else if (n == "pool") ctx->pool = value ? 1 : 0;
@@ -1249,6 +1289,44 @@ int pc_hip_sample_photons(pc_hip_ctx *ctx, uint64_t seed, int64_t n, const int64
 	return status;
 }
 
+/* where the launch for slots [lo, ...) of a run of n_total slots stores its images: see pc_kargs::img */
+static void pc_set_img(const pc_hip_ctx *ctx, pc_kargs &a, long long lo, long long n_total, bool keep, bool planes)
+{
+	const long long ne = ctx->host.pm.n_energies, rec = PC_N_FIELDS + ne;
+	if (!keep) { a.img = a.img_w = nullptr; a.img_ss = a.img_fs = a.img_ws = 0; return; }
+	if (planes) {
+		a.img = ctx->d_soa + lo; a.img_ss = 1; a.img_fs = n_total;
+		a.img_w = ctx->d_soa + (long long)PC_N_FIELDS*n_total + lo*ne; a.img_ws = ne;
+	} else {
+		a.img = ctx->d_img + lo*rec; a.img_ss = rec; a.img_fs = 1;
+		a.img_w = a.img + PC_N_FIELDS; a.img_ws = rec;
+	}
+}
+
+/* device plane buffer for a run of n_slots (see pc_soa_kernel) */
+static int pc_soa_ensure(pc_hip_ctx *ctx, long long n_slots)
+{
+	if (ctx->d_soa && ctx->soa_slots >= n_slots) return PC_HIP_OK;
+	if (ctx->d_soa) (void)hipFree(ctx->d_soa);
+	ctx->d_soa = nullptr; ctx->soa_slots = 0;
+	const size_t bytes = ((size_t)PC_N_FIELDS + (size_t)ctx->host.pm.n_energies) * (size_t)n_slots * sizeof(double);
+	if (hipMalloc(&ctx->d_soa, bytes) != hipSuccess) { (void)hipGetLastError(); ctx->d_soa = nullptr; return PC_HIP_ERR_MEMORY; }
+	ctx->soa_slots = n_slots;
+	return PC_HIP_OK;
+}
+
+/* records of slots [lo, lo + count) of the current run -> planes (pitch = the run's n_slots), on `stream` */
+static int pc_soa_launch(pc_hip_ctx *ctx, hipStream_t stream, long long lo, long long count, long long n_total)
+{
+	const int ne = ctx->host.pm.n_energies;
+	const size_t lds = (size_t)PC_SOA_TILE*(PC_N_FIELDS + ne)*sizeof(double);
+	if (lds > 65536) return PC_HIP_ERR_INVALID;
+	const unsigned blocks = (unsigned)((count + PC_SOA_TILE - 1)/PC_SOA_TILE);
+	hipLaunchKernelGGL(pc_soa_kernel, dim3(blocks), dim3(256), lds, stream, ctx->d_img, ctx->d_soa, lo, count, n_total, ne);
+	PC_HIP_CHECK(hipGetLastError());
+	return PC_HIP_OK;
+}
+
 /* First slot of part k of `parts`.  The fetch of the images can start when the first part is done and has the last part
  * left when the kernel ends, so with three or more parts the first and the last are half the size of the others. */
 static long long pc_part_begin(long long n_slots, int parts, int k)
@@ -1273,7 +1351,12 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 	pc_kargs a;
 	pc_fill_common(ctx, a);
 	ctx->img_valid = 0;
-	if (keep_images) {
+	/* option "plane_images" (set by polycap_source_get_transmission_efficiencies): the kernels store the planes of struct
+	 * _polycap_images themselves -- 18 scattered 8-byte stores per exit photon instead of two contiguous pieces of a record,
+	 * 5 % of the HBM bandwidth at most -- and the fetch is a plain copy of planes into the caller's pinned memory */
+	const bool planes = keep_images && ctx->plane_images && pc_soa_ensure(ctx, n_slots) == PC_HIP_OK;
+	ctx->run_planes = planes ? 1 : 0;
+	if (keep_images && !planes) {
 		if (ctx->img_slots < n_slots) {
 			if (ctx->d_img) PC_HIP_CHECK(hipFree(ctx->d_img));
 			ctx->d_img = nullptr; ctx->img_slots = 0;
@@ -1282,7 +1365,6 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 				return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_run: could not allocate the image planes; use keep_images=0");
 			ctx->img_slots = n_slots;
 		}
-		a.img = ctx->d_img;
 	}
 	PC_HIP_CHECK(hipMemsetAsync(ctx->d_totals, 0, ctx->totals_bytes, ctx->stream));
 	a.seed = seed; a.max_attempts = max_attempts; a.keep_images = keep_images ? 1 : 0;
@@ -1316,7 +1398,7 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 	for (int k = 0; k < parts && status == PC_HIP_OK; k++) {
 		const long long lo = pc_part_begin(n_slots, parts, k), hi = pc_part_begin(n_slots, parts, k + 1);
 		a.slot0 = slot0 + lo; a.n_slots = hi - lo;
-		a.img = keep_images ? ctx->d_img + (size_t)lo*rec : nullptr;
+		pc_set_img(ctx, a, lo, n_slots, keep_images != 0, planes);
 		if (parts > 1) {
 			a.work = ctx->d_work + k;
 			ctx->stream = (k & 1) ? ctx->stream2 : main_stream;
@@ -1360,6 +1442,7 @@ int pc_hip_transmission_run_leak(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, 
 		ctx->img_slots = n_slots;
 	}
 	ctx->n_parts = 1;
+	ctx->run_planes = 0;
 	ctx->leak_seed = seed; ctx->leak_slot0 = slot0; ctx->leak_n_slots = n_slots;
 	ctx->leak_max_attempts = max_attempts; ctx->leak_keep_images = keep_images ? 1 : 0;
 	/* record buffer: events per slot grow with the number of energies (a leak is kept while ANY energy holds >= 1e-4):
@@ -1467,6 +1550,74 @@ int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6])
 	return PC_HIP_OK;
 }
 
+/* see pc_fetch_images.  Returns PC_HIP_OK, an error, or 1 when the direct path cannot be used */
+static int pc_fetch_planes_direct(pc_hip_ctx *ctx, int64_t first, int64_t count, void *const *planes, double *weights)
+{
+	const size_t ne = (size_t)ctx->host.pm.n_energies;
+	const long long n_total = ctx->run_slots;
+	if (!ctx->run_planes && ((size_t)PC_SOA_TILE*(PC_N_FIELDS + ne)*sizeof(double) > 65536 || pc_soa_ensure(ctx, n_total) != PC_HIP_OK)) return 1;
+	if (!ctx->fetch_stream) PC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking));
+	if (!ctx->ev_sync) PC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_sync, hipEventDisableTiming));
+	const bool timing = getenv("POLYCAP_TIMING") != nullptr;
+	auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t_begin = now_ms();
+	/* pin the destinations */
+	std::vector<void *> pinned;
+	auto unpin = [&]() { for (void *p : pinned) (void)hipHostUnregister(p); pinned.clear(); };
+	for (int k = 0; k <= PC_N_FIELDS; k++) {
+		void *p = (k < PC_N_FIELDS) ? planes[k] : (void *)weights;
+		if (!p) continue;
+		const size_t bytes = (size_t)count*sizeof(double)*(k < PC_N_FIELDS ? 1 : ne);
+		if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+			(void)hipGetLastError();
+			if (ctx->run_planes) continue;        /* planes are all there is: this destination is copied unpinned (slower, still right) */
+			unpin();
+			return 1;
+		}
+		pinned.push_back(p);
+	}
+	const double t_pinned = now_ms();
+	int status = PC_HIP_OK;
+	const int parts = ctx->n_parts > 1 ? ctx->n_parts : 1;
+	for (int k = 0; k < parts && status == PC_HIP_OK; k++) {
+		const long long plo = (parts > 1 && k > 0) ? ctx->part_end[k - 1] : 0, phi = (parts > 1) ? ctx->part_end[k] : n_total;
+		const long long lo = std::max<long long>(plo, first), hi = std::min<long long>(phi, first + count);
+		if (hi <= lo) continue;
+		hipError_t e = hipSuccess;
+		if (parts > 1) {
+			e = hipStreamWaitEvent(ctx->fetch_stream, ctx->ev_part[k], 0);         /* traced, and turned into planes if eager */
+		} else {
+			int st = pc_hip_transmission_wait(ctx, nullptr);
+			if (st) { status = st; break; }
+		}
+		if (e == hipSuccess && !ctx->run_planes) {
+			/* the run kept records: turn the part into planes now, behind its trace */
+			int st = pc_soa_launch(ctx, ctx->fetch_stream, plo, phi - plo, n_total);
+			if (st) { status = st; break; }
+		}
+		for (int f = 0; f <= PC_N_FIELDS && e == hipSuccess; f++) {
+			if (f < PC_N_FIELDS) {
+				if (!planes[f]) continue;
+				e = hipMemcpyAsync((double *)planes[f] + (lo - first), ctx->d_soa + (size_t)f*n_total + lo, (size_t)(hi - lo)*sizeof(double),
+				                   hipMemcpyDeviceToHost, ctx->fetch_stream);
+			} else if (weights) {
+				e = hipMemcpyAsync(weights + (size_t)(lo - first)*ne, ctx->d_soa + (size_t)PC_N_FIELDS*n_total + (size_t)lo*ne,
+				                   (size_t)(hi - lo)*ne*sizeof(double), hipMemcpyDeviceToHost, ctx->fetch_stream);
+			}
+		}
+		if (e != hipSuccess) status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_transmission_images: ") + hipGetErrorString(e));
+	}
+	const double t_queued = now_ms();
+	if (hipStreamSynchronize(ctx->fetch_stream) != hipSuccess && status == PC_HIP_OK)
+		status = pc_fail(PC_HIP_ERR_RUNTIME, "pc_hip_transmission_images: the plane copies failed");
+	const double t_copied = now_ms();
+	unpin();
+	if (timing)
+		fprintf(stderr, "polycap timing [ms]: plane fetch: pin %.1f, enqueue %.1f, wait for trace + copies %.1f, unpin %.1f\n",
+		        t_pinned - t_begin, t_queued - t_pinned, t_copied - t_queued, now_ms() - t_copied);
+	return status;
+}
+
 static int pc_fetch_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const pc_hip_images *dst, double *raw)
 {
 	if (!ctx->img_valid) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: the last run kept no images");
@@ -1488,6 +1639,17 @@ static int pc_fetch_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const 
 			dst->pc_exit_dir[0], dst->pc_exit_dir[1], dst->pc_exit_elecv[0], dst->pc_exit_elecv[1],
 			dst->pc_exit_nrefl, dst->pc_exit_dtravel };
 		memcpy(planes, p, sizeof(p));
+	}
+	/* Fast path for plane destinations: the caller's planes are pinned for the duration of the call (hipHostRegister: 3 ms
+	 * for 1.4 GB of faulted-in memory) and the copy engine writes them straight from the device's plane copy of the records
+	 * (pc_soa_kernel), part by part behind the trace.  No host thread touches the data.  Anything that does not fit (a plane
+	 * that cannot be pinned, a record too long for the LDS tile) takes the staging pipeline below. */
+	if (ctx->run_planes && (!dst || raw))
+		return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_records: the last run stored planes (option plane_images); fetch them with pc_hip_transmission_images");
+	if (dst && !raw && (ctx->run_planes || (size_t)count*sizeof(double) >= ((size_t)1 << 20))) {
+		int st = pc_fetch_planes_direct(ctx, first, count, planes, dst->exit_coord_weights);
+		if (st != 1) return st;          /* 1 = not applicable (record runs only) */
+		if (ctx->run_planes) return pc_fail(PC_HIP_ERR_RUNTIME, "pc_hip_transmission_images: internal: plane run without a plane fetch");
 	}
 	/* Pipeline over chunks of <= 16 MB of records: one asynchronous copy (DMA engine, no compute units) of the chunk into
 	 * pinned host memory, then host threads turn the records of the previous chunk into the caller's SoA planes while the
@@ -1595,7 +1757,7 @@ static int pc_transmission_enqueue_leak(pc_hip_ctx *ctx)
 {
 	pc_kargs a;
 	pc_fill_common(ctx, a);
-	a.img = ctx->leak_keep_images ? ctx->d_img : nullptr;
+	pc_set_img(ctx, a, 0, ctx->leak_n_slots, ctx->leak_keep_images != 0, false);
 	a.seed = ctx->leak_seed; a.slot0 = ctx->leak_slot0; a.n_slots = ctx->leak_n_slots;
 	a.max_attempts = ctx->leak_max_attempts; a.keep_images = ctx->leak_keep_images;
 	return ctx->host.pm.generic_src ? pc_leak_enqueue<PC_MODE_SRC_GENERIC>(ctx, a, ctx->leak_n_slots, ctx->leak_capacity_used)

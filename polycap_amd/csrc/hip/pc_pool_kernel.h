@@ -150,7 +150,7 @@ pc_trace_pool_kernel(pc_kargs a)
 	pc_tables T;
 	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.hexd = l_hexd; T.idz = l_idz; T.ext = a.g_ext;
 	T.mg = ldsg;
-	const long long rec = PC_N_FIELDS + 1;
+	const long long fs = a.img_fs, ss = a.img_ss, ws = a.img_ws;      /* strides of the image store: records or planes (pc_kargs) */
 	const pc_params &Pm = a.pm;
 
 	pc_photon<1> ph;
@@ -226,28 +226,28 @@ pc_trace_pool_kernel(pc_kargs a)
 					f_w = (unsigned long long)(w * PC_FIX_SCALE);
 					if (a.keep_images) {
 						/* src/polycap-source.c:900-923; cos(alpha) of the start vectors was left in the record by the launch */
-						double *r = a.img + slot*rec;
-						const double cosalpha0 = __longlong_as_double((long long)__hip_atomic_load((unsigned long long *)(r + PC_F_EEVX),
+						double *r = a.img + slot*ss;
+						const double cosalpha0 = __longlong_as_double((long long)__hip_atomic_load((unsigned long long *)(r + PC_F_EEVX*fs),
 						                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-						r[PC_F_WEIGHTS] = w;
+						a.img_w[slot*ws] = w;
 						double t = (Pm.z_end - ph.Pz) / ph.dz;
 						double ex = ph.Px + ph.dx*t, ey = ph.Py + ph.dy*t, ez = ph.Pz + ph.dz*t;
-						r[PC_F_EXITX] = ex; r[PC_F_EXITY] = ey; r[PC_F_EXITZ] = ez;
-						r[PC_F_EDIRX] = ph.dx; r[PC_F_EDIRY] = ph.dy;
+						r[PC_F_EXITX*fs] = ex; r[PC_F_EXITY*fs] = ey; r[PC_F_EXITZ*fs] = ez;
+						r[PC_F_EDIRX*fs] = ph.dx; r[PC_F_EDIRY*fs] = ph.dy;
 						const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
 						double tx = ph.ex*c_ae + ph.dx*c_be, ty = ph.ey*c_ae + ph.dy*c_be, tz = ph.ez*c_ae + ph.dz*c_be;
 						pc_norm3(tx, ty, tz);
-						r[PC_F_EEVX] = round(tx); r[PC_F_EEVY] = round(ty);
-						((long long *)r)[PC_F_NREFL] = ph.irefl;
+						r[PC_F_EEVX*fs] = round(tx); r[PC_F_EEVY*fs] = round(ty);
+						((long long *)r)[PC_F_NREFL*fs] = ph.irefl;
 						double lx = ex - ph.Px, ly = ey - ph.Py, lz = Pm.z_end - ph.Pz;
-						r[PC_F_DTRAVEL] = ph.dtravel + sqrt(lx*lx + ly*ly + lz*lz);
+						r[PC_F_DTRAVEL*fs] = ph.dtravel + sqrt(lx*lx + ly*ly + lz*lz);
 					}
 					L.state = LS_NEED_SLOT;
 				} else {
 					L.attempt++;
 					if (L.attempt >= a.max_attempts) {
 						f_failed = 1;
-						if (a.keep_images) { a.img[slot*rec + PC_F_WEIGHTS] = 0.; a.img[slot*rec + PC_F_EEVX] = 0.; }
+						if (a.keep_images) { a.img_w[slot*ws] = 0.; a.img[slot*ss + PC_F_EEVX*fs] = 0.; }
 						L.state = LS_NEED_SLOT;
 					} else {
 						L.state = LS_START;
@@ -288,14 +288,14 @@ pc_trace_pool_kernel(pc_kargs a)
 					/* src/polycap-source.c:779-798 */
 					const double cosalpha0 = s.ex*s.dx + s.ey*s.dy + s.ez*s.dz;
 					const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
-					double *r = a.img + slot*rec;
-					r[PC_F_SRCX] = s.srcx; r[PC_F_SRCY] = s.srcy;
-					r[PC_F_STARTX] = s.x; r[PC_F_STARTY] = s.y;
-					r[PC_F_SDIRX] = s.dx; r[PC_F_SDIRY] = s.dy;
+					double *r = a.img + slot*ss;
+					r[PC_F_SRCX*fs] = s.srcx; r[PC_F_SRCY*fs] = s.srcy;
+					r[PC_F_STARTX*fs] = s.x; r[PC_F_STARTY*fs] = s.y;
+					r[PC_F_SDIRX*fs] = s.dx; r[PC_F_SDIRY*fs] = s.dy;
 					double tx = s.ex*c_ae + s.dx*c_be, ty = s.ey*c_ae + s.dy*c_be, tz = s.ez*c_ae + s.dz*c_be;
 					pc_norm3(tx, ty, tz);
-					r[PC_F_SEVX] = round(tx); r[PC_F_SEVY] = round(ty);
-					r[PC_F_EEVX] = cosalpha0;      /* parked here until the photon leaves the optic (read back above) */
+					r[PC_F_SEVX*fs] = round(tx); r[PC_F_SEVY*fs] = round(ty);
+					r[PC_F_EEVX*fs] = cosalpha0;      /* parked here until the photon leaves the optic (read back above) */
 				}
 			}
 			u_not_trans += (unsigned long long)__popcll(__ballot(f_not_trans));

@@ -235,8 +235,8 @@ static int pc_cache_prepare(pc_ctx_cache *c, polycap_description *description, s
 				if (energies[i] > hi) hi = energies[i];
 			}
 			warned = 1;
-			fprintf(stderr, "polycap (%s): xraylib (libxrl) not found; optical constants for %g-%g keV come from the %s provider, "
-				"which is approximate away from 10 keV.  Install xraylib for the reference's values, or set POLYCAP_OPTCONST=builtin to accept the table.\n",
+			fprintf(stderr, "polycap (%s): xraylib (libxrl) not found; optical constants for %g-%g keV come from %s, "
+				"approximate away from 10 keV.  Install xraylib for the reference's values, or set POLYCAP_OPTCONST=builtin to accept the table.\n",
 				caller, lo, hi, pc_optconst_provider());
 		}
 	}

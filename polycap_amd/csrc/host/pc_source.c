@@ -457,9 +457,13 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 	if (group != NULL) {
 		status = pc_hip_group_set_option(group, "run_parts", parts);
 		if (status == PC_HIP_OK)
+			status = pc_hip_group_set_option(group, "plane_images", 1);
+		if (status == PC_HIP_OK)
 			status = pc_hip_group_run(group, seed, n_photons, max_attempts, keep_images);
 	} else {
 		status = pc_hip_set_option(ctx, "run_parts", parts);
+		if (status == PC_HIP_OK)
+			status = pc_hip_set_option(ctx, "plane_images", leak_calc ? 0 : 1);   /* the result object wants planes: let the kernel write them */
 		if (status == PC_HIP_OK)
 			status = leak_calc ? pc_hip_transmission_run_leak(ctx, seed, 0, n_photons, max_attempts, 1)
 			                   : pc_hip_transmission_run(ctx, seed, 0, n_photons, max_attempts, keep_images);

@@ -35,6 +35,29 @@ def test_forwarding_headers_compile(tmp_path):
                            "-o", str(tmp_path / "t.o")])
 
 
+def build_dropin_client(tmp_path):
+    """tests/c/dropin_client.c: a C program written against include/polycap.h only, linked to libpolycap.so"""
+    import subprocess
+    exe = str(tmp_path / "dropin_client")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "dropin_client.c"), "-L", os.path.join(ROOT, "polycap_amd", "lib"), "-lpolycap", "-lm",
+                           "-Wl,-rpath," + os.path.join(ROOT, "polycap_amd", "lib"), "-o", exe])
+    return exe
+
+
+def test_c_client_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    """The C client of the drop-in API compiles warning-free against the public header; without a GPU its argument checks
+    still behave like the reference's and the first call that needs the trace reports the missing device."""
+    import subprocess
+    import polycap_amd
+    exe = build_dropin_client(tmp_path)
+    if polycap_amd.device_count() > 0:
+        return
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, POLYCAP_OPTCONST="builtin"))
+    assert r.returncode == 1 and "no HIP device available" in r.stderr
+    assert r.stderr.count("check failed") == 1          # only the run itself; the error-convention checks before it pass
+
+
 def test_no_device_fails_loudly():
     """Without a GPU the trace entry points must fail, never fall back to a CPU path."""
     import numpy as np

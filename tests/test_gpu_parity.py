@@ -682,3 +682,48 @@ def test_reference_loop_check_get_photon_launch_vs_driver(pa, known):
     print("loop check: %d launched, %d transmitted in %.1f s (%.0f us per get_photon + launch); loop %s driver %s"
           % (phot_ini, phot_transm, dt, 1e6 * dt / phot_ini, np.round(w_tot, 4), np.round(curve, 4)))
     assert np.all(np.abs(curve - w_tot) <= 0.0075)
+
+
+def test_c_client_of_the_drop_in_api(pa, tmp_path):
+    """tests/c/dropin_client.c -- a C program against include/polycap.h as a user of the reference would write it -- linked
+    to libpolycap.so: the reference's seven-energy curve, getter sanity checks, launch return codes, the get_photon+launch
+    loop against the driver and the error convention (reference tests/source.c, tests/photon.c)."""
+    import os
+    import subprocess
+    from tests.test_abi_symbols import build_dropin_client
+    exe = build_dropin_client(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, POLYCAP_OPTCONST="builtin", POLYCAP_SEED="20000"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "all checks passed" in r.stdout
+
+
+def test_plane_images_equal_records(pa, oracle):
+    """Option "plane_images" (what polycap_source_get_transmission_efficiencies uses): the kernels store the planes of
+    struct _polycap_images themselves and the fetch is a copy of planes into the caller's pinned arrays.  Same bits as the
+    record store, for one energy (pool kernel), seven (register weights) and twelve (weights in memory), whole and in
+    parts, full and partial fetches; the record fetch refuses a plane run."""
+    cases = [make_pair(oracle, "xos1", source=(2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.0))[2],
+             make_pair(oracle, "ellip", energies=(5.0, 8.0, 11.0, 14.0, 17.0, 20.0, 25.0))[2],
+             make_pair(oracle, "xos1", energies=np.linspace(3.0, 30.0, 12))[2]]
+    for prob in cases:
+        n = 300_000 if prob.n_energies == 1 else 120_000
+        with pa.TraceContext(prob) as ctx:
+            ctx.run(13, 7, n, keep_images=True)
+            ref = ctx.image_planes(0, n)
+            rt = ctx.totals()
+            for parts in (1, 3):
+                ctx.set_option("plane_images", 1)
+                ctx.set_option("run_parts", parts)
+                ctx.run(13, 7, n, keep_images=True)
+                p = ctx.image_planes(0, n)
+                q = ctx.image_planes(1001, n - 5000)
+                t = ctx.totals()
+                with pytest.raises(pa.HipError):
+                    ctx.images(0, 10)
+                ctx.set_option("plane_images", 0)
+                ctx.set_option("run_parts", 1)
+                assert np.array_equal(p["planes"], ref["planes"], equal_nan=True) and np.array_equal(p["exit_weights"], ref["exit_weights"])
+                assert np.array_equal(p["nrefl"], ref["nrefl"])
+                assert np.array_equal(q["planes"], ref["planes"][:, 1001:n - 3999], equal_nan=True)
+                assert np.array_equal(q["exit_weights"], ref["exit_weights"][1001:n - 3999])
+                assert np.array_equal(t["counters"][:4], rt["counters"][:4]) and np.array_equal(t["sumw_fixed"], rt["sumw_fixed"])
