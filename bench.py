@@ -4,7 +4,8 @@
 One "step" = one pass of the hot path over one batch: polycap_source_get_transmission_efficiencies for
 --photons exit-photon slots per GPU (default 1e7 = BASELINE config C2) on the xos1 optic at 10 keV, image planes
 kept in HBM, followed by the one RCCL all-reduce of the per-energy histogram.  Inputs (profile tables, optical
-constants, source parameters) are resident in HBM before the timed region; outputs stay in HBM.
+constants, source parameters) are resident in HBM before the timed region; outputs (totals and the 18 image planes of
+struct _polycap_images, written by the kernel itself) stay in HBM.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -113,6 +114,7 @@ def main():
     ne = prob.n_energies
     keep_images = not args.no_images
     ctx = polycap_amd.TraceContext(prob, dev_index)
+    ctx.set_option("plane_images", 1)     # the image layout polycap_source_get_transmission_efficiencies runs with (planes, not records)
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))

@@ -81,7 +81,12 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
  *   "run_parts"        a transmission run that keeps images is traced as this many consecutive launches on two streams,
  *                      so that pc_hip_transmission_images can fetch finished parts while later ones run (default 1;
  *                      polycap_source_get_transmission_efficiencies uses 4 from 2e6 photons on)
- *   "fetch_threads"    host threads that turn fetched image records into the caller's planes (0 = min(16, cores))
+ *   "plane_images"     1 = a run that keeps images stores the planes of pc_hip_images itself (no records): pc_hip_transmission_images
+ *                      is then a copy-engine transfer into the caller's planes, pinned for the duration of the call;
+ *                      pc_hip_transmission_records is not available for such a run.  0 (default) = one record per slot,
+ *                      turned into planes on the device when pc_hip_transmission_images asks for them
+ *   "batch_reflections" many-energy source runs: sweep a photon's weights once per four reflections (default 1)
+ *   "fetch_threads"    host threads of the staging fallback of the image fetch (0 = min(16, cores))
  *   leak runs: "leak_max_depth" (stack frames per lane = walls one photon may cross), "leak_stack_mb" (HBM for those
  *                      stacks), "leak_capacity" (leak record buffer, 0 = automatic; a run that outgrows it is repeated). */
 POLYCAP_EXTERN int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value);

@@ -42,7 +42,7 @@ def test_committed_counters_are_readable():
     for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "FETCH_SIZE", "WRITE_SIZE"):
         assert s[k] > 0
     t = (s["FETCH_SIZE"] + s["WRITE_SIZE"]) * 1024.0
-    assert 1.4e9 < t < 4e9                   # algorithmic 1.44 GB per launch; measured 3.4 GB
+    assert 1.4e9 < t < 8e9                   # algorithmic 1.44 GB per launch; measured 6.1 GB with planes (3.4 GB with records)
     # the summary belongs to the default command only: other sizes, histogram-only runs and the lane kernel get none
     assert bench.pmc_summary(1000, True, True) is None and bench.pmc_summary(10_000_000, False, True) is None
     assert bench.pmc_summary(10_000_000, True, False) is None and bench.valu_issue(None, 27.0) is None
