@@ -1550,13 +1550,28 @@ int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6])
 	return PC_HIP_OK;
 }
 
+/* The stream of the image copies.  HIP multiplexes a process's streams over a few hardware queues (4 by default): with one
+ * more context alive in the process the copies of a finished part landed in the queue of the next part's kernel and waited
+ * for it (40 -> 54 ms per 1e7 photons through the C API, scripts/analysis/api_time2.py).  A stream of the highest priority
+ * gets a queue of its own class, apart from the kernels' queues. */
+static hipError_t pc_fetch_stream_ensure(pc_hip_ctx *ctx)
+{
+	if (ctx->fetch_stream) return hipSuccess;
+	int least = 0, greatest = 0;
+	if (!getenv("POLYCAP_FETCH_PRIORITY_OFF") && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least
+	    && hipStreamCreateWithPriority(&ctx->fetch_stream, hipStreamNonBlocking, greatest) == hipSuccess)
+		return hipSuccess;
+	(void)hipGetLastError();
+	return hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking);
+}
+
 /* see pc_fetch_images.  Returns PC_HIP_OK, an error, or 1 when the direct path cannot be used */
 static int pc_fetch_planes_direct(pc_hip_ctx *ctx, int64_t first, int64_t count, void *const *planes, double *weights)
 {
 	const size_t ne = (size_t)ctx->host.pm.n_energies;
 	const long long n_total = ctx->run_slots;
 	if (!ctx->run_planes && ((size_t)PC_SOA_TILE*(PC_N_FIELDS + ne)*sizeof(double) > 65536 || pc_soa_ensure(ctx, n_total) != PC_HIP_OK)) return 1;
-	if (!ctx->fetch_stream) PC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking));
+	PC_HIP_CHECK(pc_fetch_stream_ensure(ctx));
 	if (!ctx->ev_sync) PC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_sync, hipEventDisableTiming));
 	const bool timing = getenv("POLYCAP_TIMING") != nullptr;
 	auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1674,7 +1689,7 @@ static int pc_fetch_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const 
 	}
 	for (int k = 0; k < 2; k++)
 		if (!ctx->ev_fetch[k]) PC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fetch[k], hipEventDisableTiming));
-	if (!ctx->fetch_stream) PC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking));
+	PC_HIP_CHECK(pc_fetch_stream_ensure(ctx));
 	int nthreads = ctx->fetch_threads;
 	if (nthreads <= 0) {
 		const unsigned hw = std::thread::hardware_concurrency();
