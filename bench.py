@@ -165,7 +165,7 @@ def main():
         alg_bytes = n_local * (BYTES_PER_EXIT_PHOTON + 8 * ne) if keep_images else 8.0 * (ne + 6)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         sched = ctx.phase_stats()
-        pool = "pool=0" not in args.opt
+        pool = "pool=1" in args.opt           # the LDS photon pool kernel (the default up to v14) is an option now
         pmc = pmc_summary(n_local, keep_images, pool)
         # useful fp64 work of the kernel as executed (after certified skipping), from its own counters: a march lane-step is
         # 6 FMA = 12 flop; a segment visit ~150 flop-equivalents (quadratic, 7 div, 1-2 sqrt, hexagon tests) and a reflection
@@ -227,13 +227,17 @@ def main():
 
 def pmc_summary(n_local, keep_images, pool):
     """The committed counter summary applies to the default command only (same workload, same kernel)."""
-    if n_local != 10_000_000 or not keep_images or not pool:
+    if n_local != 10_000_000 or not keep_images:
         return None
     try:
         with open(PMC_SUMMARY) as f:
-            return json.load(f)
+            summary = json.load(f)
     except Exception:
         return None
+    kernel = summary.get("meta", {}).get("kernel", "")
+    if ("pc_trace_pool_kernel" in kernel) != bool(pool):
+        return None
+    return summary
 
 
 def valu_issue(pmc, kernel_ms):

@@ -66,7 +66,13 @@ struct pc_params {
 
 /* block-certificate margins of one start node (pc_march_ok): base and chord deviation of zh for strides PC_L1 and PC_L2;
  * +inf where the stride does not fit before the end of the profile */
-struct pc_marg4 { float mb1, md1, mb2, md2; };
+/* Block-certificate data of one start node, one 16-byte read per march step: mb12 = margin bases of strides PC_L1 (high half)
+ * and PC_L2 (low half) as the upper 16 bits of a float, rounded up; md1, md2 = chord deviations of zh over the two blocks;
+ * r2 = twice the largest capillary radius of the PC_L2 block (which contains the PC_L1 block).  All rounded up and, except the
+ * deviations, inflated by PC_MARGIN_INFLATE at build time (pc_problem.h). */
+struct pc_marg4 { unsigned int mb12; float md1, md2, r2; };
+
+PC_HD float pc_bits_as_float(unsigned int u) { return __builtin_bit_cast(float, u); }
 
 /* profile tables.  z/cap/zh/cap2 are the MARCH tables (LDS on the device), ext is only read on events. */
 struct pc_tables {
@@ -90,6 +96,9 @@ struct pc_tables {
 #endif
 #define PC_MARGIN_INFLATE 1.0000038f   /* 1 + 2^-18 */
 #ifndef PC_LV_LATER
+#ifndef PC_CREEP
+#define PC_CREEP 1     /* a failed probe at stride PC_L1 goes to the EVENT phase, which walks the last segments itself (pc_event_pre) */
+#endif
 #define PC_LV_LATER 2  /* widest level a flight after a reflection starts with */
 #endif
 
@@ -435,10 +444,11 @@ PC_HD int pc_march_ok(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph
 	/* Block certificate (stride L > 1).  Over nodes i..i+L let zh_c, R_c be the chords of zh and cap between the two
 	 * end nodes, Dzh and DR the largest deviations of the (piecewise linear) tables from those chords, dR = cap[i+L]-cap[i].
 	 * With q = q_c - k*dev_zh and R = R_c + dev_R:
-	 *     g <= g_c + 2 R_max (|k| Dzh + DR) + (|k| Dzh)^2,     g_c <= max(g(z_i), g(z_i+L)) + dR^2/4
-	 * so g < 0 on all L segments when both end values are below -(mb + |k| md (2 R_max + |k| md)), with
-	 * mb = dR^2/4 + 2 R_max DR + m and md = Dzh tabulated per start node (rounded up to float).  L = 1 is the plain
-	 * single-segment certificate with margin adj. */
+	 *     g <= g_c + 2 R_blk (|k| Dzh + DR) + (|k| Dzh)^2,     g_c <= max(g(z_i), g(z_i+L)) + dR^2/4
+	 * (|q_c| < R_c <= R_blk wherever g_c < 0, R_blk = the largest radius of the block: near the narrow end of a tapered optic
+	 * a third of the global maximum), so g < 0 on all L segments when both end values are below
+	 * -(mb + |k| md (2 R_blk + |k| md)), with mb = dR^2/4 + 2 R_blk DR + m, md = Dzh and 2 R_blk tabulated per start node
+	 * (pc_marg4, rounded up).  L = 1 is the plain single-segment certificate with margin adj. */
 	/* ph.lv caps the stride for this flight (lowered after a failed probe); take the widest stride whose margin the
 	 * current node already satisfies */
 	const int cap = ph.lv;
@@ -455,8 +465,8 @@ PC_HD int pc_march_ok(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph
 		const pc_marg4 g = T.mg[i0];
 		const float knf = (float)ph.kn * PC_MARGIN_INFLATE;
 		const float kd1 = knf * g.md1, kd2 = knf * g.md2;
-		const float m1 = fmaf(kd1, Pm.two_rmaxf + kd1, g.mb1 * PC_MARGIN_INFLATE);
-		const float m2 = fmaf(kd2, Pm.two_rmaxf + kd2, g.mb2 * PC_MARGIN_INFLATE);
+		const float m1 = fmaf(kd1, g.r2 + kd1, pc_bits_as_float(g.mb12 & 0xffff0000u));
+		const float m2 = fmaf(kd2, g.r2 + kd2, pc_bits_as_float(g.mb12 << 16));
 		if (cap >= 1 && C0f < -m1) { lv = 1; marg = m1; }
 		if (cap >= 2 && C0f < -m2) { lv = 2; marg = m2; }
 	}
@@ -477,7 +487,16 @@ PC_HD int pc_march_ok(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph
 		ok &= !pc_outside_hexd(h0, px, py);
 	}
 	if (ok) { ph.C0 = C1; ph.i = i1; return 1; }
-	if (lv > 0) { ph.lv = lv - 1; return 1; }     /* far node not certified: shorter strides for the rest of this flight */
+	if (lv > 0) {
+#if PC_CREEP
+		/* The node PC_L1 segments ahead is not certified: the wall is (nearly always) within those segments.  Walking up to it
+		 * one certified segment per step costs 1.8 steps per flight plus this one; pc_event_pre does that walk in straight-line
+		 * code in front of its literal visit instead (ph.lv == 3 asks for it). */
+		if (lv == 1) { ph.lv = 3; return 0; }
+#endif
+		ph.lv = lv - 1;                             /* far node not certified: shorter strides for the rest of this flight */
+		return 1;
+	}
 	return 0;
 }
 
@@ -731,8 +750,23 @@ struct pc_hit {
 template <int NE>
 PC_HD int pc_event_pre(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &ph, pc_hit &h)
 {
-	const int i = ph.i;
+	int i = ph.i;
 	const int nmax = Pm.nmax;
+	if (ph.lv == 3) {
+		/* sent here by a failed probe at stride PC_L1 (pc_march_ok): certified single segments up to the first one that is
+		 * not -- the same certificate, values and order as single march steps -- then the literal visit of that one.
+		 * Nodes i+1 .. i+PC_L1 exist: the probe looked at the last of them (which may still pass the single-segment margin). */
+		ph.lv = 0;
+		const float adjf = Pm.adjf;
+#pragma unroll
+		for (int k = 1; k <= PC_L1; k++) {
+			const double C = pc_node_C(T, ph, i + 1);
+			if (!(((float)ph.C0 < -adjf) & ((float)C < -adjf))) break;
+			ph.C0 = C;
+			i++;
+		}
+		ph.i = i;
+	}
 	if (i >= nmax) { ph.rc = 1; return PC_ST_DONE; }           /* :1312-1313 -> launch returns 1 */
 
 	/* :1263 capillary axis inside the optic at both ends of the segment (only boundary capillaries can fail) */

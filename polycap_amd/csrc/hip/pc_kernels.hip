@@ -75,7 +75,7 @@ struct pc_totals {             /* device-resident totals of one run */
 
 struct pc_kargs {
 	const double *g_z, *g_cap, *g_zh, *g_cap2, *g_hexd, *g_idz, *g_ext;
-	const float *g_mb1, *g_md1, *g_mb2, *g_md2;
+	const pc_marg4 *g_mg;         /* block-certificate record per start node (pc_problem.h) */
 	const pc_energy_const *ec;
 	const double *ec_soa;         /* the same constants field-major [6][n_energies]: coalesced loads in the cooperative sweeps */
 	pc_params pm;
@@ -100,6 +100,7 @@ struct pc_kargs {
 	int lds_pend;                 /* NE == 0, more than 32 energies: reflections wait in LDS (PC_KB x 3 doubles per lane, behind the
 	                               * constants) and a photon's weights are swept once per PC_KB reflections */
 	int pool_event_min;           /* pool kernel: photons waiting for an EVENT phase that make it run before anything else */
+	int event_march;              /* pool kernel: march steps taken right after an EVENT phase, while the wave is still full of fresh flights */
 	int pool_refill;              /* pool kernel: lanes that must be free before a march burst tops itself up from the pool */
 	double *wscratch;             /* NE==0: n_energies * total_threads */
 	long long total_threads;
@@ -155,7 +156,7 @@ pc_trace_kernel(pc_kargs a)
 		l_cap2[k] = a.g_cap2[k];
 		l_hexd[k] = a.g_hexd[k];
 		l_idz[k] = a.g_idz[k];
-		ldsg[k] = pc_marg4{a.g_mb1[k], a.g_md1[k], a.g_mb2[k], a.g_md2[k]};
+		ldsg[k] = a.g_mg[k];
 	}
 	if (NE != 1 && a.lds_acc)
 		for (int k = threadIdx.x; k < 2*a.pm.n_energies; k += blockDim.x) l_acc[k] = 0ull;
@@ -824,18 +825,23 @@ struct pc_hip_ctx {
 	double *d_tables = nullptr;            /* z, cap, zh, cap2, hexd, idz, ext: 7 x npts */
 	pc_energy_const *d_ec = nullptr;
 	double *d_ec_soa = nullptr;
-	float *d_ftables = nullptr;            /* mb1, md1, mb2, md2: 4 x npts */
+	pc_marg4 *d_mg = nullptr;              /* block-certificate records, npts */
 	/* options */
 	int literal = 0;
-	int event_threshold = 20;      /* tuned on MI355X, xos1 10 keV (scripts/sweep_opts.sh: flat within 1.5 % over 8..32 x 2..16 x 8..32) */
+	int event_threshold = 48;      /* lanes that must be marching for a MARCH burst to run before the waiting EVENTs.  With the short flights of
+	                                * the current march (5.5 steps) the wave works almost in lockstep: 20 -> 44..48 is 26.2 -> 23.3 ms on xos1
+	                                * (profiles/r02/kernel_history.md); optics with long flights (cone.inp) prefer ~24, ellip_l9 with roughness ~32 */
 	int new_threshold = 2;
 	int march_burst = 16;
 	int blocks_per_cu = 2;
 	int block_size = 512;
-	int pool = 1;                  /* single-energy source runs on profiles of up to 1024 points: per-wave photon pool in LDS (pc_pool_kernel.h), +6 % */
+	int pool = 0;                  /* 1: single-energy source runs on profiles of up to 1024 points use the per-wave photon pool in LDS (pc_pool_kernel.h).
+	                                * Was the default up to v14 (+6 %); since flights take 5.5 steps instead of 8.8 the exchanges with the pool cost more
+	                                * than its fuller phases save (26.3 ms against 23.3 ms for the one-photon-per-lane kernel) */
 	int pool_refill = 20;
 	int pool_march_min = 16;
 	int pool_event_min = 48;
+	int event_march = 0;
 	int pool_new_min = 48;
 	int lds_ec = 1;                /* many-energy runs: per-energy constants in LDS, one 1024-thread workgroup per CU */
 	int batch_reflections = 1;     /* more than 32 energies: sweep a photon's weights once per PC_KB reflections */
@@ -907,7 +913,7 @@ static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
 	a.g_z = ctx->d_tables; a.g_cap = ctx->d_tables + npts; a.g_zh = ctx->d_tables + 2*npts;
 	a.g_cap2 = ctx->d_tables + 3*npts; a.g_hexd = ctx->d_tables + 4*npts; a.g_idz = ctx->d_tables + 5*npts;
 	a.g_ext = ctx->d_tables + 6*npts;
-	a.g_mb1 = ctx->d_ftables; a.g_md1 = ctx->d_ftables + npts; a.g_mb2 = ctx->d_ftables + 2*npts; a.g_md2 = ctx->d_ftables + 3*npts;
+	a.g_mg = ctx->d_mg;
 	a.ec = ctx->d_ec;
 	a.ec_soa = ctx->d_ec_soa;
 	a.pm = ctx->host.pm;
@@ -977,6 +983,7 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		a.total_threads = (long long)grid * PQ_BLOCK;
 		a.event_threshold = ctx->pool_march_min;
 		a.pool_event_min = ctx->pool_event_min;
+		a.event_march = ctx->event_march;
 		a.new_threshold = ctx->pool_new_min;
 		if (ctx->rec_ev0) PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
 		pc_launch_pool<MODE>(ctx, a, grid);
@@ -1035,7 +1042,7 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->d_tables) (void)hipFree(ctx->d_tables);
 	if (ctx->d_ec) (void)hipFree(ctx->d_ec);
 	if (ctx->d_ec_soa) (void)hipFree(ctx->d_ec_soa);
-	if (ctx->d_ftables) (void)hipFree(ctx->d_ftables);
+	if (ctx->d_mg) (void)hipFree(ctx->d_mg);
 	if (ctx->d_totals) (void)hipFree(ctx->d_totals);
 	if (ctx->d_img) (void)hipFree(ctx->d_img);
 	if (ctx->d_soa) (void)hipFree(ctx->d_soa);
@@ -1086,10 +1093,8 @@ int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ou
 	const std::vector<double> *src[7] = { &ctx->host.z, &ctx->host.cap, &ctx->host.zh, &ctx->host.cap2, &ctx->host.hexd, &ctx->host.idz, &ctx->host.ext };
 	for (int k = 0; k < 7; k++)
 		PC_CTX_CHECK(hipMemcpy(ctx->d_tables + k*npts, src[k]->data(), npts*sizeof(double), hipMemcpyHostToDevice));
-	PC_CTX_CHECK(hipMalloc(&ctx->d_ftables, 4*npts*sizeof(float)));
-	const std::vector<float> *fsrc[4] = { &ctx->host.mb1, &ctx->host.md1, &ctx->host.mb2, &ctx->host.md2 };
-	for (int k = 0; k < 4; k++)
-		PC_CTX_CHECK(hipMemcpy(ctx->d_ftables + k*npts, fsrc[k]->data(), npts*sizeof(float), hipMemcpyHostToDevice));
+	PC_CTX_CHECK(hipMalloc(&ctx->d_mg, npts*sizeof(pc_marg4)));
+	PC_CTX_CHECK(hipMemcpy(ctx->d_mg, ctx->host.mg.data(), npts*sizeof(pc_marg4), hipMemcpyHostToDevice));
 	{
 		/* at least 8 entries: the register-weight kernels read NE constants whatever n_energies is (surplus = copies of the last) */
 		std::vector<pc_energy_const> ecp(ctx->host.ec);
@@ -1134,6 +1139,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "fetch_threads") { if (value < 0 || value > 256) return pc_fail(PC_HIP_ERR_INVALID, "fetch_threads must be in [0,256]"); ctx->fetch_threads = (int)value; }
 	else if (n == "pool") ctx->pool = value ? 1 : 0;
 	else if (n == "pool_refill") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "pool_refill must be in [1,64]"); ctx->pool_refill = (int)value; }
+	else if (n == "event_march") { if (value < 0 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "event_march must be in [0,64]"); ctx->event_march = (int)value; }
 	else if (n == "pool_event_min") { if (value < 1 || value > 128) return pc_fail(PC_HIP_ERR_INVALID, "pool_event_min must be in [1,128]"); ctx->pool_event_min = (int)value; }
 	else if (n == "pool_new_min") { if (value < 1 || value > 128) return pc_fail(PC_HIP_ERR_INVALID, "pool_new_min must be in [1,128]"); ctx->pool_new_min = (int)value; }
 	else if (n == "pool_march_min") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "pool_march_min must be in [1,64]"); ctx->pool_march_min = (int)value; }

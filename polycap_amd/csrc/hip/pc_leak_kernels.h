@@ -47,7 +47,7 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 		lds[4*PITCH + k] = a.g_hexd[k];
 		lds[5*PITCH + k] = a.g_idz[k];
 		lds[6*PITCH + k] = a.g_ext[k];
-		ldsg[k] = pc_marg4{a.g_mb1[k], a.g_md1[k], a.g_mb2[k], a.g_md2[k]};
+		ldsg[k] = a.g_mg[k];
 	}
 	__syncthreads();
 	pc_tables T;

@@ -138,7 +138,7 @@ pc_trace_pool_kernel(pc_kargs a)
 		l_cap2[k] = a.g_cap2[k];
 		l_hexd[k] = a.g_hexd[k];
 		l_idz[k] = a.g_idz[k];
-		ldsg[k] = pc_marg4{a.g_mb1[k], a.g_md1[k], a.g_mb2[k], a.g_md2[k]};
+		ldsg[k] = a.g_mg[k];
 	}
 	const int lane = threadIdx.x & (PC_WAVE - 1);
 	const int wave = threadIdx.x / PC_WAVE;
@@ -205,6 +205,22 @@ pc_trace_pool_kernel(pc_kargs a)
 			st_event += 1; st_event_l += (unsigned)__popcll(__ballot(L.state == LS_EVENT));
 			if (L.state == LS_EVENT)
 				L.state = pc_event(T, Pm, a.ec, ph);
+			/* The wave is now full of flights that have just begun, most of them a few steps long: their first steps are taken
+			 * here, at the EVENT phase's lane count, instead of in a MARCH burst after an exchange with the pool. */
+			if (a.event_march > 0) {
+				if (L.state == LS_MARCH && ph.first)
+					L.state = pc_march_step(T, Pm, ph);
+				unsigned int lanes = 0;
+				int u = 0;
+				for (; u < a.event_march; u++) {
+					const unsigned int nm = (unsigned)__popcll(__ballot(L.state == LS_MARCH));
+					if (nm == 0) break;
+					lanes += nm;
+					if (L.state == LS_MARCH)
+						L.state = pc_march_step_hot(T, Pm, ph);
+				}
+				st_march += (unsigned)u; st_march_l += lanes;
+			}
 		} else {
 			/* ---------------- NEW: finalise finished photons, hand out slots, sample + entrance tests */
 			st_new += 1; st_new_l += (unsigned)__popcll(__ballot(L.state == LS_DONE || L.state == LS_NEED_SLOT || L.state == LS_START));

@@ -113,7 +113,9 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 			dzh = dzh*(1. + 1e-9) + 1e-12*std::fabs(t.zh[i]);
 			dr = dr*(1. + 1e-9) + 1e-12*capmax;
 			double dR = p->cap[i+L] - p->cap[i];
-			double base = 0.25*dR*dR + pm.two_rmax*dr + m;
+			double rblk = 0.;
+			for (int j = i; j <= i + L; j++) rblk = std::fmax(rblk, p->cap[j]);
+			double base = 0.25*dR*dR + 2.*rblk*dr + m;
 			float fb = (float)base, fd = (float)dzh;
 			if ((double)fb < base) fb = std::nextafter(fb, HUGE_VALF);
 			if ((double)fd < dzh) fd = std::nextafter(fd, HUGE_VALF);
@@ -121,8 +123,22 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 			md[i] = fd;
 		}
 	}
+	/* packed per start node (pc_marg4): margin bases inflated, rounded up and cut to their upper 16 bits (rounded up again:
+	 * positive floats order like their bit patterns; infinity stays infinity), twice the largest radius of the wider block */
 	t.mg.resize(n);
-	for (int i = 0; i < n; i++) t.mg[i] = pc_marg4{t.mb1[i], t.md1[i], t.mb2[i], t.md2[i]};
+	for (int i = 0; i < n; i++) {
+		unsigned int half[2];
+		for (int lvl = 0; lvl < 2; lvl++) {
+			const float v = std::nextafter(((lvl == 0) ? t.mb1[i] : t.mb2[i]) * PC_MARGIN_INFLATE, HUGE_VALF);
+			unsigned int u = __builtin_bit_cast(unsigned int, v);
+			if (u & 0xffffu) u = (u & 0xffff0000u) + 0x10000u;
+			half[lvl] = u >> 16;
+		}
+		double rblk = 0.;
+		for (int j = i; j < n && j <= i + PC_L2; j++) rblk = std::fmax(rblk, p->cap[j]);
+		const float r2 = std::nextafter((float)(2.*rblk), HUGE_VALF) * PC_MARGIN_INFLATE;
+		t.mg[i] = pc_marg4{(half[0] << 16) | half[1], t.md1[i], t.md2[i], std::nextafter(r2, HUGE_VALF)};
+	}
 	pm.bnd_thresh = ratio + 1e-9;
 
 	t.ec.resize(p->n_energies);

@@ -7,6 +7,8 @@
  * never linked into, loaded by or shipped with libpolycap: the product has no CPU trace path.
  */
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -235,6 +237,62 @@ int emul_transmission(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int
 	}
 	counters[0] = c0; counters[1] = c1; counters[2] = c2; counters[3] = c3;
 	sumw_fixed[0] = (uint64_t)tot; sumw_fixed[1] = (uint64_t)(tot >> 64);
+	return 0;
+}
+
+/* Analysis aid (scripts/analysis/flight_stats.py): how the march steps of a run distribute over flights.  hist[256]: flights
+ * by number of march steps (last bin: >= 255); steps_by[8]: steps that advanced by 1 / PC_L1 / PC_L2 segments, probes that
+ * failed at stride PC_L2 / PC_L1 (the stride is lowered), steps that ended in an EVENT, first-segment steps, flights. */
+static int64_t dbg_adv1_lvcap, dbg_adv1_end;
+int emul_flight_stats(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int64_t n_slots, int64_t *hist, int64_t *steps_by)
+{
+	Emul E;
+	int r = setup(p, 0, E);
+	if (r) return r;
+	for (int k = 0; k < 256; k++) hist[k] = 0;
+	for (int k = 0; k < 8; k++) steps_by[k] = 0;
+	for (int64_t j = 0; j < n_slots; j++) {
+		for (uint32_t attempt = 0; attempt < (1u << 20); attempt++) {
+			pc_start s;
+			if (E.t.pm.generic_src) pc_sample_photon<true>(E.t.pm, seed, (uint64_t)(slot0 + j), attempt, s);
+			else pc_sample_photon<false>(E.t.pm, seed, (uint64_t)(slot0 + j), attempt, s);
+			pc_photon<1> ph; ph.wmem = nullptr; ph.wstride = 0;
+			int st = pc_launch_init(E.T, E.t.pm, ph, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez);
+			int64_t in_flight = 0;
+			while (st != PC_ST_DONE) {
+				if (st == PC_ST_MARCH) {
+					const int i0 = ph.i, first = ph.first, lv0 = ph.lv;
+					const double C0b = ph.C0;
+					st = pc_march_step(E.T, E.t.pm, ph);
+					if (getenv("PC_FS_TRACE") && j < 3) {
+						const pc_marg4 g = E.T.mg[i0];
+						const float knf = (float)ph.kn;
+						fprintf(stderr, "slot %lld refl %d: i %d first %d cap %d C0 %.3e  m1 %.3e m2 %.3e (md1 %.2e r2 %.2e kn %.1f) -> i %d cap %d st %d\n", (long long)j, ph.irefl, i0, first, lv0, C0b,
+						        (double)(knf*g.md1*(g.r2 + knf*g.md1) + pc_bits_as_float(g.mb12 & 0xffff0000u)), (double)(knf*g.md2*(g.r2 + knf*g.md2) + pc_bits_as_float(g.mb12 << 16)), (double)g.md1, (double)g.r2, (double)knf, ph.i, ph.lv, st);
+					}
+					in_flight++;
+					if (first) steps_by[6]++;
+					else if (st == PC_ST_MARCH) {
+						const int adv = ph.i - i0;
+						if (adv == 1) { steps_by[0]++; if (getenv("PC_FS_DEBUG") && ph.lv > 0) dbg_adv1_lvcap++; if (getenv("PC_FS_DEBUG") && i0 + PC_L1 > E.t.pm.nmax) dbg_adv1_end++; }
+						else if (adv == PC_L1) steps_by[1]++;
+						else if (adv == PC_L2) steps_by[2]++;
+						else if (adv == 0) steps_by[(lv0 == 2 && ph.lv == 1) ? 3 : 4]++;
+					} else if (st == PC_ST_EVENT) steps_by[5]++;
+				} else {
+					st = pc_event(E.T, E.t.pm, E.t.ec.data(), ph);
+					if (ph.first || st == PC_ST_DONE) {      /* a reflection (a new flight begins) or the end */
+						hist[in_flight < 255 ? in_flight : 255]++;
+						steps_by[7]++;
+						in_flight = 0;
+					}
+				}
+			}
+			if (in_flight) { hist[in_flight < 255 ? in_flight : 255]++; steps_by[7]++; }
+			if (ph.rc == 1 && pc_in_exit_window(E.t.pm, ph)) break;
+		}
+	}
+	if (getenv("PC_FS_DEBUG")) fprintf(stderr, "adv1 with stride cap > 0: %lld, adv1 near the end of the profile: %lld\n", (long long)dbg_adv1_lvcap, (long long)dbg_adv1_end);
 	return 0;
 }
 
