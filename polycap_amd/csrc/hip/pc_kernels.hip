@@ -38,7 +38,8 @@
 #define PC_WAVE 64
 #define PC_MAX_PITCH 2048      /* largest profile kept in static LDS: (6 x 8 + 4 x 4) B x 2048 = 128 KB */
 #ifndef PC_MARCH_UNROLL
-#define PC_MARCH_UNROLL 8      /* march steps between two ballots of the burst loop (4: 32.5 ms, 8: 31.9 ms, 12: 33.1 ms; scripts/ab_flags.sh) */
+#define PC_MARCH_UNROLL 4      /* march steps between two ballots of the burst loop.  With march_stop = 8 (a burst goes on while 8 lanes march):
+                                * 3: 23.6 ms, 4: 23.4, 5: 23.9, 8: 24.1 (scripts/ab_build.sh, xos1 10 keV, 1e7 slots) */
 #endif
 #define PC_KE 5                /* energies per lane whose weights are in flight together in a cooperative sweep */
 #ifndef PC_KB
@@ -85,6 +86,7 @@ struct pc_kargs {
 	int keep_images;
 	int event_threshold;
 	int march_burst;
+	int march_stop;               /* a burst goes on while at least this many lanes march (<= event_threshold, which starts it) */
 	pc_totals *totals;
 	unsigned long long *work;     /* the launch's work counter (relative slot index handed out next) */
 	unsigned long long *sumw;     /* 2*n_energies */
@@ -297,7 +299,7 @@ pc_trace_kernel(pc_kargs a)
 					const int cM = __popcll(__ballot(state == LS_MARCH));
 					st_march += PC_MARCH_UNROLL; st_march_l += lanes_in_burst;
 					if (cM == 0) break;
-					if (cM < a.event_threshold && (cM != nM || do_new || nE > 0)) break;
+					if (cM < a.march_stop && (cM != nM || do_new || nE > 0)) break;
 				}
 			}
 		} else if (nE > 0 && !(do_new && nN > nE)) {
@@ -833,6 +835,7 @@ struct pc_hip_ctx {
 	                                * (profiles/r02/kernel_history.md); optics with long flights (cone.inp) prefer ~24, ellip_l9 with roughness ~32 */
 	int new_threshold = 2;
 	int march_burst = 16;
+	int march_stop = 8;            /* a burst that has started goes on while this many lanes march (0: event_threshold): most flights end within it */
 	int blocks_per_cu = 2;
 	int block_size = 512;
 	int pool = 0;                  /* 1: single-energy source runs on profiles of up to 1024 points use the per-wave photon pool in LDS (pc_pool_kernel.h).
@@ -921,6 +924,7 @@ static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
 	a.event_threshold = ctx->event_threshold;
 	a.new_threshold = ctx->new_threshold;
 	a.march_burst = ctx->march_burst;
+	a.march_stop = (ctx->march_stop > 0 && ctx->march_stop < ctx->event_threshold) ? ctx->march_stop : ctx->event_threshold;
 	a.pool_refill = ctx->pool_refill;
 	a.totals = ctx->d_totals;
 	a.work = &ctx->d_totals->next_slot;
@@ -1129,6 +1133,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	if (n == "literal_march") ctx->literal = value ? 1 : 0;
 	else if (n == "event_threshold") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "event_threshold must be in [1,64]"); ctx->event_threshold = (int)value; }
 	else if (n == "new_threshold") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "new_threshold must be in [1,64]"); ctx->new_threshold = (int)value; }
+	else if (n == "march_stop") { if (value < 0 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "march_stop must be in [0,64]"); ctx->march_stop = (int)value; }
 	else if (n == "march_burst") { if (value < 1) return pc_fail(PC_HIP_ERR_INVALID, "march_burst must be >= 1"); ctx->march_burst = (int)value; }
 	else if (n == "block_size") { if (value < 64 || value > PC_BLOCK || (value % 64) != 0) return pc_fail(PC_HIP_ERR_INVALID, "block_size must be a multiple of 64 up to the compiled maximum"); ctx->block_size = (int)value; }
 	else if (n == "blocks_per_cu") { if (value < 1 || value > 8) return pc_fail(PC_HIP_ERR_INVALID, "blocks_per_cu must be in [1,8]"); ctx->blocks_per_cu = (int)value; }
