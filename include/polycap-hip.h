@@ -74,10 +74,11 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
 
 /* Tuning / test switches (none of them changes a result):
  *   "literal_march"    1 = visit every segment with the reference's full quadratic, 0 = certified skipping (default)
- *   "event_threshold", "new_threshold", "march_burst", "blocks_per_cu", "block_size"   scheduler / launch shape
+ *   "event_threshold", "march_stop", "new_threshold", "march_burst", "blocks_per_cu", "block_size"   scheduler / launch shape:
+ *                      a MARCH burst starts when event_threshold lanes march (48) and goes on while march_stop do (8)
  *   "lds_ec"           many energies: per-energy constants staged in LDS (default 1)
  *   "pool", "pool_refill", "pool_march_min", "pool_event_min", "pool_new_min"   single-energy source runs: the kernel
- *                      that parks 64 more photons per wave in LDS (pc_pool_kernel.h); "pool" 1 by default, 0 = one photon per lane
+ *                      that parks 64 more photons per wave in LDS (pc_pool_kernel.h); "pool" 0 by default = one photon per lane
  *   "run_parts"        a transmission run that keeps images is traced as this many consecutive launches on two streams,
  *                      so that pc_hip_transmission_images can fetch finished parts while later ones run (default 1;
  *                      polycap_source_get_transmission_efficiencies uses 4 from 2e6 photons on)
