@@ -801,8 +801,8 @@ PC_HD int pc_event_pre(const pc_tables &T, const pc_params &Pm, pc_photon<NE> &p
 		}
 	}
 	/* :1315-1324 */
-	double rx = hx - ph.Px, ry = hy - ph.Py, rz = hz - ph.Pz;
-	ph.dtravel += sqrt(fma(rx, rx, fma(ry, ry, rz*rz)));
+	/* |hit - P| along a unit direction = (hz - P.z)/dz: the reference's square root (:1315-1318) without the root */
+	ph.dtravel += (hz - ph.Pz) * ph.idzd;
 	ph.Px = hx; ph.Py = hy; ph.Pz = hz;
 	if (fabs(cosalfa) > 1.0) { ph.rc = -1; return PC_ST_DONE; } /* :1325-1327 */
 	/* :1330-1333 rescan: last node index < nmax with z <= hit z (z strictly increasing, z_i <= hz <= z_i+1) */

@@ -15,7 +15,8 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libpc_emul.so")
+        extra = os.environ.get("PC_EMUL_FLAGS", "").split()      # analysis builds (other strides ...): a library of their own
+        so = os.path.join(_HERE, "libpc_emul.so" if not extra else "libpc_emul_%08x.so" % (hash(tuple(extra)) & 0xffffffff))
         srcs = [os.path.join(_HERE, "pc_emul.cpp"),
                 os.path.join(_ROOT, "polycap_amd", "csrc", "hip", "pc_device.h"),
                 os.path.join(_ROOT, "polycap_amd", "csrc", "hip", "pc_problem.h"),
@@ -25,7 +26,7 @@ def lib():
                                    "-ffp-contract=off", "-mfma", "-fopenmp",   # same IEEE operation sequence as the gfx950 build (fma only where written)
                                    "-I" + os.path.join(_ROOT, "include"),
                                    "-I" + os.path.join(_ROOT, "polycap_amd", "csrc", "hip"),
-                                   "-o", so, srcs[0]])
+                                   "-o", so, srcs[0]] + extra)
         L = C.CDLL(so)
         L.emul_launch_batch.argtypes = [C.POINTER(ProblemS), C.c_int, C.c_int, C.c_int64, c_double_p, c_double_p, c_double_p,
                                         C.POINTER(C.c_int32), c_double_p, c_double_p, c_double_p, c_double_p,
