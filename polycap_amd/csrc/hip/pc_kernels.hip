@@ -676,6 +676,7 @@ pc_trace_kernel(pc_kargs a)
 }
 
 #include "pc_pool_kernel.h"
+#include "pc_producer_kernel.h"
 
 /* Image records (one contiguous record of 17 + n_energies doubles per slot) -> the planes of struct _polycap_images: 17
  * planes of n_total doubles each, then the weights as [slot][n_energies].  A workgroup stages PC_SOA_TILE records in LDS
@@ -838,6 +839,14 @@ struct pc_hip_ctx {
 	int march_stop = 8;            /* a burst that has started goes on while this many lanes march (0: event_threshold): most flights end within it */
 	int blocks_per_cu = 2;
 	int block_size = 512;
+	int producer = -1;             /* single-energy source runs with a launching wave per workgroup (pc_producer_kernel.h): 1 always, 0 never,
+	                                * -1 when photons live long enough for one launching wave per CU to keep up (refl_per_launch, below):
+	                                * -5 % on xos1 and ellip_l9, but 2.3x slower on cone.inp, whose photons hardly reflect */
+	double refl_per_launch = -1.;  /* reflections of transmitted photons per launch in the last source run of this context; < 0: not known.
+	                                * A big first run is preceded by a probe of 32768 slots (results unused) */
+	int in_probe = 0;
+	int last_run_plain = 0;        /* the last run was pc_hip_transmission_run (its counters tell refl_per_launch) */
+	int producer_new_min = 2, producer_new_first = 8;
 	int pool = 0;                  /* 1: single-energy source runs on profiles of up to 1024 points use the per-wave photon pool in LDS (pc_pool_kernel.h).
 	                                * Was the default up to v14 (+6 %); since flights take 5.5 steps instead of 8.8 the exchanges with the pool cost more
 	                                * than its fuller phases save (26.3 ms against 23.3 ms for the one-photon-per-lane kernel) */
@@ -978,6 +987,27 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 	/* more than 32 energies: PC_KB reflections per sweep of a photon's weights (their geometry waits in LDS: 96 B per lane) */
 	a.lds_pend = (a.lds_ec && ne > 32 && ctx->batch_reflections && MODE != PC_MODE_EXPLICIT) ? 1 : 0;   /* source runs only: an explicit
 	                                       * photon reports its state at the absorbing reflection, which the speculation overwrites */
+	if constexpr (MODE != PC_MODE_EXPLICIT) {
+		const pc_params &pm = ctx->host.pm;
+		const bool want_producer = ctx->producer == 1 || (ctx->producer < 0 && !ctx->in_probe && ctx->refl_per_launch >= PC3_MIN_REFL);
+		if (want_producer && pm.n_energies == 1 && !ctx->literal && pm.nmax + 1 <= PC3_PITCH && a.max_attempts <= (1u << 24)
+		    && pm.n_shells < 16000. && a.n_slots < (1ll << 39)) {
+			const long long per_block = (long long)PC3_CONSUMERS*PC_WAVE;
+			long long want = (n_items + per_block - 1) / per_block;
+			const long long per_cu = (PC3_BLOCK > 512) ? 1 : 2;
+			int grid = (int)(want < per_cu*ctx->n_cu ? want : per_cu*ctx->n_cu);
+			if (grid < 1) grid = 1;
+			a.total_threads = (long long)grid * PC3_BLOCK;
+			a.event_threshold = ctx->event_threshold;
+			a.new_threshold = ctx->producer_new_min;
+			a.pool_event_min = ctx->producer_new_first;
+			if (ctx->rec_ev0) PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+			hipLaunchKernelGGL((pc_trace_producer_kernel<MODE>), dim3(grid), dim3(PC3_BLOCK), 0, ctx->stream, a);
+			PC_HIP_CHECK(hipGetLastError());
+			if (ctx->rec_ev1) PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+			return PC_HIP_OK;
+		}
+	}
 	if (pc_pool_applies<MODE>(ctx, a)) {
 		/* one 1024-thread workgroup per CU; a wave holds 64 + PQ_P photons */
 		const long long per_block = (long long)PQ_WAVES*(PC_WAVE + PQ_P);
@@ -1091,6 +1121,8 @@ int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ou
 	PC_CTX_CHECK(hipGetDeviceProperties(&prop, device));
 	ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	PC_CTX_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+	if (const char *e = getenv("POLYCAP_PRODUCER"))          /* tests: force (1) or forbid (0) the launching-wave kernel */
+		if (*e == '0' || *e == '1') ctx->producer = *e - '0';
 	PC_CTX_CHECK(hipEventCreate(&ctx->ev0));
 	PC_CTX_CHECK(hipEventCreate(&ctx->ev1));
 	PC_CTX_CHECK(hipMalloc(&ctx->d_tables, 7*npts*sizeof(double)));
@@ -1143,6 +1175,9 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "run_parts") { if (value < 1 || value > PC_MAX_PARTS) return pc_fail(PC_HIP_ERR_INVALID, "run_parts must be in [1,16]"); ctx->run_parts = (int)value; }
 	else if (n == "fetch_threads") { if (value < 0 || value > 256) return pc_fail(PC_HIP_ERR_INVALID, "fetch_threads must be in [0,256]"); ctx->fetch_threads = (int)value; }
 	else if (n == "pool") ctx->pool = value ? 1 : 0;
+	else if (n == "producer") { if (value < -1 || value > 1) return pc_fail(PC_HIP_ERR_INVALID, "producer must be -1 (automatic), 0 or 1"); ctx->producer = (int)value; }
+	else if (n == "producer_new_min") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "producer_new_min must be in [1,64]"); ctx->producer_new_min = (int)value; }
+	else if (n == "producer_new_first") { if (value < 1 || value > 65) return pc_fail(PC_HIP_ERR_INVALID, "producer_new_first must be in [1,65]"); ctx->producer_new_first = (int)value; }
 	else if (n == "pool_refill") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "pool_refill must be in [1,64]"); ctx->pool_refill = (int)value; }
 	else if (n == "event_march") { if (value < 0 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "event_march must be in [0,64]"); ctx->event_march = (int)value; }
 	else if (n == "pool_event_min") { if (value < 1 || value > 128) return pc_fail(PC_HIP_ERR_INVALID, "pool_event_min must be in [1,128]"); ctx->pool_event_min = (int)value; }
@@ -1359,6 +1394,16 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 	if (max_attempts < 1) max_attempts = 1;
 	PC_HIP_CHECK(hipSetDevice(ctx->device));
 	const size_t ne = (size_t)ctx->host.pm.n_energies;
+	if (ctx->producer < 0 && ctx->refl_per_launch < 0. && !ctx->in_probe && ne == 1 && n_slots >= 2000000) {
+		/* first big run of the context: 32768 slots with the default kernel tell how long photons live here (3 ms, results unused) */
+		ctx->in_probe = 1;
+		int64_t c[6];
+		int st = pc_hip_transmission_run(ctx, seed, slot0, 32768, max_attempts, 0);
+		if (st == PC_HIP_OK) st = pc_hip_transmission_totals(ctx, nullptr, c, nullptr);
+		ctx->in_probe = 0;
+		if (st != PC_HIP_OK && st != PC_HIP_ERR_ATTEMPTS) return st;
+	}
+	ctx->last_run_plain = 1;
 	pc_kargs a;
 	pc_fill_common(ctx, a);
 	ctx->img_valid = 0;
@@ -1454,6 +1499,7 @@ int pc_hip_transmission_run_leak(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, 
 	}
 	ctx->n_parts = 1;
 	ctx->run_planes = 0;
+	ctx->last_run_plain = 0;
 	ctx->leak_seed = seed; ctx->leak_slot0 = slot0; ctx->leak_n_slots = n_slots;
 	ctx->leak_max_attempts = max_attempts; ctx->leak_keep_images = keep_images ? 1 : 0;
 	/* record buffer: events per slot grow with the number of energies (a leak is kept while ANY energy holds >= 1e-4):
@@ -1541,6 +1587,8 @@ int pc_hip_transmission_totals(pc_hip_ctx *ctx, double *sum_weights, int64_t cou
 	const size_t ne = (size_t)ctx->host.pm.n_energies;
 	if (counters)
 		for (int k = 0; k < 6; k++) counters[k] = (int64_t)t->counters[k];
+	if (t->counters[5] > 0 && ctx->last_run_plain)
+		ctx->refl_per_launch = (double)t->counters[3] / (double)t->counters[5];     /* what the next run chooses its kernel by */
 	for (size_t e = 0; e < ne; e++) {
 		if (sum_weights) sum_weights[e] = pc_hip_fixed_to_double(sw[2*e], sw[2*e+1]);
 		if (sumw_fixed) { sumw_fixed[2*e] = sw[2*e]; sumw_fixed[2*e+1] = sw[2*e+1]; }
