@@ -165,8 +165,8 @@ def main():
         alg_bytes = n_local * (BYTES_PER_EXIT_PHOTON + 8 * ne) if keep_images else 8.0 * (ne + 6)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         sched = ctx.phase_stats()
-        pool = "pool=1" in args.opt           # the LDS photon pool kernel (the default up to v14) is an option now
-        pmc = pmc_summary(n_local, keep_images, pool)
+        kernel = ctx.last_kernel() or "pc_trace_kernel"        # what traced the timed steps (the context picks it, hip.py)
+        pmc = pmc_summary(n_local, keep_images, kernel)
         # useful fp64 work of the kernel as executed (after certified skipping), from its own counters: a march lane-step is
         # 6 FMA = 12 flop; a segment visit ~150 flop-equivalents (quadratic, 7 div, 1-2 sqrt, hexagon tests) and a reflection
         # ~120 + 100 per energy; against the 78.6 TFLOP/s vector-fp64 peak of the MI355X
@@ -203,7 +203,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 if pmc else None,
-                         "kernel": "pc_trace_pool_kernel<0>" if pool else "pc_trace_kernel<1,0,1024>", "kernel_ms": avg_ms,
+                         "kernel": {"pc_trace_kernel": "pc_trace_kernel<1,0,1024>"}.get(kernel, kernel + "<0>"), "kernel_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "fp64-VALU/divergence-bound by construction (SURVEY 8d): 144 B per exit photon; traffic and the "
                                  "VALU counters come from the committed rocprofv3 --pmc summary of this command (FETCH_SIZE + "
@@ -225,7 +225,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_summary(n_local, keep_images, pool):
+def pmc_summary(n_local, keep_images, kernel):
     """The committed counter summary applies to the default command only (same workload, same kernel)."""
     if n_local != 10_000_000 or not keep_images:
         return None
@@ -234,9 +234,8 @@ def pmc_summary(n_local, keep_images, pool):
             summary = json.load(f)
     except Exception:
         return None
-    kernel = summary.get("meta", {}).get("kernel", "")
-    if ("pc_trace_pool_kernel" in kernel) != bool(pool):
-        return None
+    if (kernel + "<") not in summary.get("meta", {}).get("kernel", ""):
+        return None                       # the counters belong to another kernel
     return summary
 
 

@@ -77,6 +77,8 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
  *   "event_threshold", "march_stop", "new_threshold", "march_burst", "blocks_per_cu", "block_size"   scheduler / launch shape:
  *                      a MARCH burst starts when event_threshold lanes march (48) and goes on while march_stop do (8)
  *   "lds_ec"           many energies: per-energy constants staged in LDS (default 1)
+ *   "producer"         single-energy source runs with a launching wave per workgroup (pc_producer_kernel.h): 1 always, 0 never,
+ *                      -1 (default) when photons live long enough (see pc_hip_last_kernel)
  *   "pool", "pool_refill", "pool_march_min", "pool_event_min", "pool_new_min"   single-energy source runs: the kernel
  *                      that parks 64 more photons per wave in LDS (pc_pool_kernel.h); "pool" 0 by default = one photon per lane
  *   "run_parts"        a transmission run that keeps images is traced as this many consecutive launches on two streams,
@@ -172,6 +174,10 @@ POLYCAP_EXTERN int pc_hip_group_totals(pc_hip_group *group, int reduce, double *
 /* Scheduler statistics of the last transmission run (diagnostics): {march steps, march lane-steps, event phases,
  * event lanes, new phases, new lanes}, summed over all waves; lanes/phases = average active lanes per phase. */
 POLYCAP_EXTERN int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6]);
+/* Which kernel traced the last source run: 0 one photon per lane (pc_trace_kernel), 1 LDS photon pool (option "pool"),
+ * 2 launching wave per workgroup (option "producer"; by default chosen when the photons of the context's last run made at
+ * least 4 reflections per launch -- a first run of 2e6 slots or more is preceded by a 32768-slot probe).  -1: none yet. */
+POLYCAP_EXTERN int pc_hip_last_kernel(pc_hip_ctx *ctx);
 
 /* efficiency formula of src/polycap-source.c:1066-1076 from (summed) totals */
 POLYCAP_EXTERN void pc_hip_efficiencies(size_t n_energies, const double *sum_weights, const int64_t counters[6], double *efficiencies);

@@ -142,6 +142,8 @@ def lib():
     L.pc_hip_transmission_records.restype = C.c_int
     L.pc_hip_phase_stats.argtypes = [C.c_void_p, c_int64_p]
     L.pc_hip_phase_stats.restype = C.c_int
+    L.pc_hip_last_kernel.argtypes = [C.c_void_p]
+    L.pc_hip_last_kernel.restype = C.c_int
     L.pc_hip_device_synchronize.argtypes = [C.c_void_p]
     L.pc_hip_device_synchronize.restype = C.c_int
     L.pc_hip_group_create.argtypes = [P(ProblemS), C.c_int, P(C.c_int), P(C.c_void_p)]

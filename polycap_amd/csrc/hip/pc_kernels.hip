@@ -845,6 +845,7 @@ struct pc_hip_ctx {
 	double refl_per_launch = -1.;  /* reflections of transmitted photons per launch in the last source run of this context; < 0: not known.
 	                                * A big first run is preceded by a probe of 32768 slots (results unused) */
 	int in_probe = 0;
+	int last_kernel = -1;          /* pc_hip_last_kernel */
 	int last_run_plain = 0;        /* the last run was pc_hip_transmission_run (its counters tell refl_per_launch) */
 	int producer_new_min = 2, producer_new_first = 8;
 	int pool = 0;                  /* 1: single-energy source runs on profiles of up to 1024 points use the per-wave photon pool in LDS (pc_pool_kernel.h).
@@ -1003,6 +1004,7 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 			a.pool_event_min = ctx->producer_new_first;
 			if (ctx->rec_ev0) PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
 			hipLaunchKernelGGL((pc_trace_producer_kernel<MODE>), dim3(grid), dim3(PC3_BLOCK), 0, ctx->stream, a);
+			ctx->last_kernel = 2;
 			PC_HIP_CHECK(hipGetLastError());
 			if (ctx->rec_ev1) PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
 			return PC_HIP_OK;
@@ -1021,6 +1023,7 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		a.new_threshold = ctx->pool_new_min;
 		if (ctx->rec_ev0) PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
 		pc_launch_pool<MODE>(ctx, a, grid);
+		ctx->last_kernel = 1;
 		PC_HIP_CHECK(hipGetLastError());
 		if (ctx->rec_ev1) PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
 		return PC_HIP_OK;
@@ -1043,6 +1046,7 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		a.wscratch = ctx->d_wscratch;
 	}
 	if (ctx->rec_ev0) PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+	ctx->last_kernel = 0;
 	int st = (kne == 1) ? pc_launch_one<1, MODE>(ctx, a, grid) : (kne == 4) ? pc_launch_one<4, MODE>(ctx, a, grid)
 	       : (kne == 8) ? pc_launch_one<8, MODE>(ctx, a, grid) : pc_launch_one<0, MODE>(ctx, a, grid);
 	if (st) return st;
@@ -1596,6 +1600,11 @@ int pc_hip_transmission_totals(pc_hip_ctx *ctx, double *sum_weights, int64_t cou
 	if (t->counters[4] != 0)
 		return pc_fail(PC_HIP_ERR_ATTEMPTS, "pc_hip_transmission_totals: some slots exhausted max_attempts without a transmitted photon");
 	return PC_HIP_OK;
+}
+
+int pc_hip_last_kernel(pc_hip_ctx *ctx)
+{
+	return ctx ? ctx->last_kernel : -1;
 }
 
 int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6])

@@ -28,6 +28,7 @@
 #define PC3_FIELDS 11         /* x, y, dx, dy, dz, ex, ey, ez, kn, (slot, attempt), (qr, bnd) */
 #define PC3_RETRY 64          /* retry requests waiting per tracing wave */
 #define PC3_MAX_POLLS 4000000
+#define PC3_MAX_OUTSTANDING ((PC3_CONSUMERS)*(PC_WAVE + PC3_CAP) + 20)
 #define PC3_MIN_REFL 4.0      /* option "producer" = -1: reflections of transmitted photons per launch from which this kernel is used */
 #ifndef PC3_SLEEP
 #define PC3_SLEEP 127          /* the launching wave waits for room in the rings 90 % of the time: long naps (8128 clocks) */
@@ -116,10 +117,16 @@ pc_trace_producer_kernel(pc_kargs a)
 					if (lane == 0) pc3_store(&ctl.r_head[c], rh + (unsigned)n);
 				}
 			}
-			/* fresh slots for the lanes that are still without a request */
+			/* fresh slots for the lanes that are still without a request -- while the slots in flight stay below what the
+			 * lanes and the rings of launched photons hold (PC3_MAX_OUTSTANDING): with more, retry requests could fill every
+			 * retry ring while every tracing lane waits to file one and every launching lane holds one -- nobody could move */
 			if (fresh_left) {
 				const unsigned long long mFree = __ballot(!have);
-				const int nf = __popcll(mFree);
+				int nf = __popcll(mFree);
+				{
+					const int room = PC3_MAX_OUTSTANDING - (int)pc3_load(&ctl.outstanding);
+					if (nf > room) nf = (room > 0) ? room : 0;
+				}
 				if (nf > 0) {
 					const int rank = __popcll(mFree & below);
 					long long got = -1;
@@ -128,12 +135,12 @@ pc_trace_producer_kernel(pc_kargs a)
 						long long base_new = 0;
 						if (lane == 0) base_new = (long long)atomicAdd(a.work, (unsigned long long)PC_CHUNK);
 						base_new = __shfl(base_new, 0, PC_WAVE);
-						if (!have) got = (rank < left) ? (chunk_next + rank) : (base_new + (rank - left));
+						if (!have && rank < nf) got = (rank < left) ? (chunk_next + rank) : (base_new + (rank - left));
 						chunk_next = base_new + (nf - left);
 						chunk_end = base_new + PC_CHUNK;
 						if (base_new >= a.n_slots) fresh_left = 0;
 					} else {
-						if (!have) got = chunk_next + rank;
+						if (!have && rank < nf) got = chunk_next + rank;
 						chunk_next += nf;
 					}
 					const int take = (!have && got >= 0 && got < a.n_slots) ? 1 : 0;
@@ -162,7 +169,7 @@ pc_trace_producer_kernel(pc_kargs a)
 			const int nreq = __popcll(mReq);
 			{
 				/* a batch is worth its ~1000 instructions when a ring's worth of photons fits (the lanes with the lowest ranks go) */
-				const int need = (nreq < PC3_CAP) ? nreq : PC3_CAP;
+				const int need = (polls > 64) ? 1 : ((nreq < PC3_CAP) ? nreq : PC3_CAP);     /* waited long: whatever fits */
 				if (total_free < need) { __builtin_amdgcn_s_sleep(PC3_SLEEP); polls++; continue; }
 			}
 			const int go = have && (__popcll(mReq & below) < total_free);

@@ -149,6 +149,12 @@ class TraceContext:
                     i_exit=int(cnt[0]), not_entered=int(cnt[1]), not_transmitted=int(cnt[2]), sum_irefl=int(cnt[3]),
                     failed_slots=int(cnt[4]), launches=int(cnt[5]), i_start=int(cnt[0] + cnt[1] + cnt[2]))
 
+    KERNELS = {0: "pc_trace_kernel", 1: "pc_trace_pool_kernel", 2: "pc_trace_producer_kernel"}
+
+    def last_kernel(self):
+        """Name of the kernel that traced the last source run (None before the first)."""
+        return self.KERNELS.get(int(self._L.pc_hip_last_kernel(self._h)))
+
     def phase_stats(self):
         """Average active lanes per scheduler phase of the last run (diagnostics)."""
         st = np.zeros(6, dtype=np.int64)

@@ -18,9 +18,16 @@ summary = {}
 meta = {}
 for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_%s_pmc*" % tag))):
     for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        rows = [r for r in csv.DictReader(open(f)) if "pc_trace" in r["Kernel_Name"]]
+        # the trace kernel of the timed steps: the one with the most dispatches (a context's first big run is preceded by a
+        # small probe launch of the default kernel, which is not what is profiled)
+        names = collections.Counter(r["Kernel_Name"] for r in rows)
+        if not names:
+            continue
+        main = names.most_common(1)[0][0]
         agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            if "pc_trace" in r["Kernel_Name"]:
+        for r in rows:
+            if r["Kernel_Name"] == main:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta = dict(kernel=r["Kernel_Name"], VGPR=r["VGPR_Count"], SGPR=r["SGPR_Count"], LDS=r["LDS_Block_Size"],
                             grid=r["Grid_Size"], workgroup=r["Workgroup_Size"])

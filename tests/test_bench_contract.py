@@ -38,14 +38,16 @@ def test_committed_counters_are_readable():
     sys.path.insert(0, ROOT)
     import bench
     assert os.path.exists(bench.PMC_SUMMARY)
-    s = bench.pmc_summary(10_000_000, True, False)
+    with open(bench.PMC_SUMMARY) as f:
+        kernel = json.load(f)["meta"]["kernel"].split("void ")[-1].split("<")[0]
+    s = bench.pmc_summary(10_000_000, True, kernel)
     for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "FETCH_SIZE", "WRITE_SIZE"):
         assert s[k] > 0
     t = (s["FETCH_SIZE"] + s["WRITE_SIZE"]) * 1024.0
     assert 1.4e9 < t < 8e9                   # algorithmic 1.44 GB per launch; measured 6.1 GB with planes (3.4 GB with records)
     # the summary belongs to the default command only: other sizes, histogram-only runs and the lane kernel get none
-    assert bench.pmc_summary(1000, True, False) is None and bench.pmc_summary(10_000_000, False, False) is None
-    assert bench.pmc_summary(10_000_000, True, True) is None and bench.valu_issue(None, 27.0) is None
+    assert bench.pmc_summary(1000, True, kernel) is None and bench.pmc_summary(10_000_000, False, kernel) is None
+    assert bench.pmc_summary(10_000_000, True, "pc_trace_pool_kernel") is None and bench.valu_issue(None, 27.0) is None
     v = bench.valu_issue(s, 27.0)
     assert 0.5 < v["frac"] < 1.0 and 0.3 < v["lane_utilisation"] < 0.8
 

@@ -446,35 +446,56 @@ def test_many_energies_match_the_host_compile(pa, oracle, n_energies):
         assert sum(int(x) for x in np.floor(w[:, k] * 4611686018427387904.0).astype(np.uint64)) == tot
 
 
-def test_photon_pool_kernel_is_bit_identical(pa, oracle):
-    """Option "pool" (the default for single-energy source runs up to v14, an option since): photons parked in LDS are
-    exchanged between lanes (pc_pool_kernel.h).  A photon depends on (seed, slot, attempt) only and the sums are exact, so totals and every image
-    plane equal those of the one-photon-per-lane kernel ("pool" = 0)."""
+def test_pool_and_producer_kernels_are_bit_identical(pa, oracle):
+    """Options "pool" (photons parked in LDS are exchanged between lanes, pc_pool_kernel.h: the default for single-energy
+    source runs up to v14) and "producer" (a launching wave per workgroup hands launched photons to the tracing waves
+    through LDS rings, pc_producer_kernel.h: chosen automatically for long-lived photons).  A photon depends on
+    (seed, slot, attempt) only and the sums are exact, so totals and every image plane equal those of the
+    one-photon-per-lane kernel."""
     from tests.common import make_custom, MONO_CASE, SEVEN_CASE
     probs = [make_pair(oracle, "xos1")[2], make_pair(oracle, "xos1", source=(2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.0))[2],
              make_custom(oracle, **MONO_CASE)[2], make_custom(oracle, **SEVEN_CASE)[2]]
     for k, prob in enumerate(probs):
         for n, max_attempts in ((60000, 1 << 20), (37, 1 << 20), (3000, 2)):
             with pa.TraceContext(prob) as ctx:
-                ctx.set_option("pool", 0)
-                ctx.run(31 + k, 1000, n, max_attempts=max_attempts, keep_images=True)
-                ctx.wait()
-                a = ctx.totals(check=False)
-                a.update(ctx.images(0, n))
-                ctx.set_option("pool", 1)
-                ctx.run(31 + k, 1000, n, max_attempts=max_attempts, keep_images=True)
-                ctx.wait()
-                b = ctx.totals(check=False)
-                b.update(ctx.images(0, n))
-                swaps = ctx.phase_stats()
-            assert np.array_equal(a["counters"], b["counters"]) and np.array_equal(a["sumw_fixed"], b["sumw_fixed"]), (k, n)
-            assert np.array_equal(a["exit_weights"], b["exit_weights"]), (k, n)
+                res = {}
+                for name, pool, producer in (("lane", 0, 0), ("pool", 1, 0), ("producer", 0, 1)):
+                    ctx.set_option("pool", pool)
+                    ctx.set_option("producer", producer)
+                    ctx.run(31 + k, 1000, n, max_attempts=max_attempts, keep_images=True)
+                    ctx.wait()
+                    r = ctx.totals(check=False)
+                    r.update(ctx.images(0, n))
+                    assert ctx.last_kernel() == {"lane": "pc_trace_kernel", "pool": "pc_trace_pool_kernel", "producer": "pc_trace_producer_kernel"}[name]
+                    assert ctx.phase_stats()["march"]["phases"] > 0
+                    res[name] = r
+            a = res["lane"]
             done = a["exit_weights"][:, 0] > 0        # a slot that ran out of attempts has weight 0 and no defined exit planes
-            assert np.array_equal(a["images"][done], b["images"][done], equal_nan=True), (k, n)
-            assert np.array_equal(a["images"][~done, :8], b["images"][~done, :8], equal_nan=True), (k, n)
+            for name in ("pool", "producer"):
+                b = res[name]
+                assert np.array_equal(a["counters"], b["counters"]) and np.array_equal(a["sumw_fixed"], b["sumw_fixed"]), (name, k, n)
+                assert np.array_equal(a["exit_weights"], b["exit_weights"]), (name, k, n)
+                assert np.array_equal(a["images"][done], b["images"][done], equal_nan=True), (name, k, n)
+                assert np.array_equal(a["images"][~done, :8], b["images"][~done, :8], equal_nan=True), (name, k, n)
             if max_attempts == 2:
                 assert a["failed_slots"] > 0 and not done.all()
-            assert swaps["march"]["phases"] > 0
+
+
+def test_kernel_choice_by_photon_lifetime(pa, oracle):
+    """Option "producer" = -1 (default): a context's first big run is preceded by a small probe with the default kernel; the
+    launching-wave kernel then traces optics whose photons reflect often (xos1) and the default kernel the others."""
+    _, _, prob, _ = make_pair(oracle, "xos1", source=(2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.0))
+    with pa.TraceContext(prob) as ctx:
+        small = ctx.transmission(5, 0, 100_000)
+        assert ctx.last_kernel() == "pc_trace_producer_kernel" or ctx.last_kernel() == "pc_trace_kernel"
+        first = ctx.last_kernel()
+        big = ctx.transmission(5, 0, 2_100_000)
+        assert ctx.last_kernel() == "pc_trace_producer_kernel"
+        ctx.set_option("producer", 0)
+        ref = ctx.transmission(5, 0, 2_100_000)
+        assert ctx.last_kernel() == "pc_trace_kernel"
+    assert first == "pc_trace_kernel"                  # nothing known yet, and too small for a probe
+    assert np.array_equal(big["counters"], ref["counters"]) and np.array_equal(big["sumw_fixed"], ref["sumw_fixed"])
 
 
 def test_image_fetch_paths_agree_on_a_multi_energy_run(pa, oracle):
