@@ -21,6 +21,7 @@
 #endif
 #define PC3_WAVES (PC3_BLOCK / PC_WAVE)
 #define PC3_CONSUMERS (PC3_WAVES - 1)
+#define PC3_MAXCONS PC3_WAVES
 #define PC3_PITCH 1024
 #ifndef PC3_CAP
 #define PC3_CAP 28            /* launched photons waiting per tracing wave */
@@ -28,7 +29,7 @@
 #define PC3_FIELDS 11         /* x, y, dx, dy, dz, ex, ey, ez, kn, (slot, attempt), (qr, bnd) */
 #define PC3_RETRY 64          /* retry requests waiting per tracing wave */
 #define PC3_MAX_POLLS 4000000
-#define PC3_MAX_OUTSTANDING ((PC3_CONSUMERS)*(PC_WAVE + PC3_CAP) + 20)
+#define PC3_MAX_OUTSTANDING (PC3_CONSUMERS*(PC_WAVE + PC3_CAP) + 20)
 #define PC3_MIN_REFL 4.0      /* option "producer" = -1: reflections of transmitted photons per launch from which this kernel is used */
 #ifndef PC3_SLEEP
 #define PC3_SLEEP 127          /* the launching wave waits for room in the rings 90 % of the time: long naps (8128 clocks) */
@@ -58,8 +59,9 @@ pc_trace_producer_kernel(pc_kargs a)
 {
 	__shared__ double lds[6*PC3_PITCH];
 	__shared__ pc_marg4 ldsg[PC3_PITCH];
-	__shared__ double l_ring[PC3_CONSUMERS*PC3_FIELDS*PC3_CAP];
-	__shared__ unsigned long long l_retry[PC3_CONSUMERS*PC3_RETRY];
+	__shared__ double l_ring[PC3_MAXCONS*PC3_FIELDS*PC3_CAP];
+	__shared__ unsigned long long l_retry[PC3_MAXCONS*PC3_RETRY];
+	__shared__ unsigned long long l_req[PC_WAVE];      /* the launching wave's requests, one per lane: (slot << 24 | attempt) + 1, 0 = none */
 	__shared__ pc3_ctrl ctl;
 	const int npts = a.pm.nmax + 1;
 	double *l_z = lds, *l_cap = lds + PC3_PITCH, *l_zh = lds + 2*PC3_PITCH, *l_cap2 = lds + 3*PC3_PITCH, *l_hexd = lds + 4*PC3_PITCH, *l_idz = lds + 5*PC3_PITCH;
@@ -73,6 +75,7 @@ pc_trace_producer_kernel(pc_kargs a)
 		ldsg[k] = a.g_mg[k];
 	}
 	if (threadIdx.x < (int)(sizeof(pc3_ctrl)/sizeof(unsigned int))) ((unsigned int *)&ctl)[threadIdx.x] = 0u;
+	if (threadIdx.x < PC_WAVE) l_req[threadIdx.x] = 0ull;
 	__syncthreads();
 	const int lane = threadIdx.x & (PC_WAVE - 1);
 	const int wave = threadIdx.x / PC_WAVE;
@@ -87,15 +90,18 @@ pc_trace_producer_kernel(pc_kargs a)
 	unsigned long long st_march = 0, st_march_l = 0, st_event = 0, st_event_l = 0, st_new = 0, st_new_l = 0, st_batches = 0;
 	long long polls = 0;
 
-	if (wave == 0) {
-		/* ================================================================ the launching wave */
-		int have = 0;                       /* this lane holds a request */
-		long long f_slot = 0;
-		unsigned int f_att = 0;
-		long long chunk_next = 0, chunk_end = 0;
-		int fresh_left = 1;
-		for (;;) {
-			if (polls > PC3_MAX_POLLS) { if (lane == 0) atomicAdd(&ctl.failed, 1u); break; }
+	/* wave-uniform state of the launching wave */
+	long long chunk_next = 0, chunk_end = 0;
+	int fresh_left = 1;
+	/* One step of the launching wave: gather requests, launch a batch when there is room for it.  Returns 0 after a batch,
+	 * 1 when there was nothing to do or no room, 2 when the run is over, 3 when it gave up. */
+	auto producer_step = [&]() -> int {
+		unsigned long long rq = l_req[lane];
+		int have = rq != 0ull;
+		long long f_slot = have ? (long long)((rq - 1ull) >> 24) : 0;
+		unsigned int f_att = have ? (unsigned int)((rq - 1ull) & 0xffffffull) : 0u;
+		{
+			if (polls > PC3_MAX_POLLS) { if (lane == 0) atomicAdd(&ctl.failed, 1u); return 3; }
 			/* retry requests of the tracing waves, ring by ring */
 #pragma unroll 1
 			for (int c = 0; c < PC3_CONSUMERS; c++) {
@@ -151,10 +157,10 @@ pc_trace_producer_kernel(pc_kargs a)
 			}
 			const unsigned long long mReq = __ballot(have);
 			if (mReq == 0ull) {
-				if (!fresh_left && pc3_load(&ctl.outstanding) == 0u) { if (lane == 0) pc3_store(&ctl.done, 1u); break; }
-				__builtin_amdgcn_s_sleep(64);
+				if (!fresh_left && pc3_load(&ctl.outstanding) == 0u) { if (lane == 0) pc3_store(&ctl.done, 1u); return 2; }
 				polls++;
-				continue;
+				l_req[lane] = 0ull;
+				return 1;
 			}
 			/* room for every photon that may enter */
 			int myfree = 0;
@@ -170,7 +176,7 @@ pc_trace_producer_kernel(pc_kargs a)
 			{
 				/* a batch is worth its ~1000 instructions when a ring's worth of photons fits (the lanes with the lowest ranks go) */
 				const int need = (polls > 64) ? 1 : ((nreq < PC3_CAP) ? nreq : PC3_CAP);     /* waited long: whatever fits */
-				if (total_free < need) { __builtin_amdgcn_s_sleep(PC3_SLEEP); polls++; continue; }
+				if (total_free < need) { polls++; l_req[lane] = have ? ((((unsigned long long)f_slot << 24) | (unsigned long long)(f_att & 0xffffffu)) + 1ull) : 0ull; return 1; }
 			}
 			const int go = have && (__popcll(mReq & below) < total_free);
 			st_batches++;
@@ -180,7 +186,6 @@ pc_trace_producer_kernel(pc_kargs a)
 			pc_photon<1> np;
 			np.wmem = nullptr; np.wstride = 1;
 			if (go) {
-				u_launch++;
 				pc_start s;
 				pc_sample_photon<MODE == PC_MODE_SRC_GENERIC>(Pm, a.seed, (unsigned long long)(a.slot0 + f_slot), f_att, s);
 				const int st = pc_launch_init(T, Pm, np, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez);
@@ -209,8 +214,9 @@ pc_trace_producer_kernel(pc_kargs a)
 					}
 				}
 			}
-			u_not_entered += (unsigned long long)f_ne;
-			u_failed += (unsigned long long)f_fail;
+			u_launch += (unsigned long long)__popcll(__ballot(go));
+			u_not_entered += (unsigned long long)__popcll(__ballot(f_ne));
+			u_failed += (unsigned long long)__popcll(__ballot(f_fail));
 			{
 				const int nfail = __popcll(__ballot(f_fail));
 				if (nfail > 0 && lane == 0) atomicSub(&ctl.outstanding, (unsigned int)nfail);
@@ -248,9 +254,17 @@ pc_trace_producer_kernel(pc_kargs a)
 				}
 			}
 		}
-		u_launch = pc_wave_sum_u64(u_launch);
-		u_not_entered = pc_wave_sum_u64(u_not_entered);
-		u_failed = pc_wave_sum_u64(u_failed);
+		l_req[lane] = have ? ((((unsigned long long)f_slot << 24) | (unsigned long long)(f_att & 0xffffffu)) + 1ull) : 0ull;
+		return 0;
+	};
+
+	if (wave == 0) {
+		/* ================================================================ the launching wave */
+		for (;;) {
+			const int r = producer_step();
+			if (r >= 2) break;
+			if (r == 1) __builtin_amdgcn_s_sleep(PC3_SLEEP);
+		}
 	} else {
 		/* ================================================================ a tracing wave */
 		const int c = wave - 1;
@@ -440,9 +454,8 @@ pc_trace_producer_kernel(pc_kargs a)
 			atomicAdd(&a.totals->phase[2], st_event); atomicAdd(&a.totals->phase[3], st_event_l);
 			atomicAdd(&a.totals->phase[4], st_new); atomicAdd(&a.totals->phase[5], st_new_l);
 			pc_atomic_add128(a.sumw, u_acc_lo, u_acc_hi);
-		} else {
-			atomicAdd(&a.totals->phase[6], st_batches);
 		}
+		if (wave == 0) atomicAdd(&a.totals->phase[6], st_batches);
 	}
 	__syncthreads();
 	/* a wave that gave up waiting: the run is reported as failed (more failed slots than the run has slots) */
