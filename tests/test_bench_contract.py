@@ -44,7 +44,7 @@ def test_committed_counters_are_readable():
     for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "FETCH_SIZE", "WRITE_SIZE"):
         assert s[k] > 0
     t = (s["FETCH_SIZE"] + s["WRITE_SIZE"]) * 1024.0
-    assert 1.4e9 < t < 8e9                   # algorithmic 1.44 GB per launch; measured 6.1 GB with planes (3.4 GB with records)
+    assert 1.4e9 < t < 1.5e10                # algorithmic 1.44 GB per launch; measured 11.4 GB (v16: scattered 8-byte plane stores 5.8 GB, scratch of the launching wave; v15 7.7 GB, records 3.4 GB)
     # the summary belongs to the default command only: other sizes, histogram-only runs and the lane kernel get none
     assert bench.pmc_summary(1000, True, kernel) is None and bench.pmc_summary(10_000_000, False, kernel) is None
     assert bench.pmc_summary(10_000_000, True, "pc_trace_pool_kernel") is None and bench.valu_issue(None, 27.0) is None
