@@ -16,7 +16,12 @@
 
 #include <algorithm>
 
+#ifndef PC_LEAK_BLOCK
 #define PC_LEAK_BLOCK 256
+#endif
+#ifndef PC_LEAK_MIN_WAVES
+#define PC_LEAK_MIN_WAVES 1    /* waves per SIMD the register allocator leaves room for */
+#endif
 
 struct pc_leak_kargs {
 	const double *amu;             /* [n_energies] */
@@ -32,7 +37,7 @@ struct pc_leak_kargs {
 enum { PC_LM_NEED = 0, PC_LM_RUN = 1, PC_LM_IDLE = 2 };
 
 template <int MODE, int PITCH>
-__global__ void __launch_bounds__(PC_LEAK_BLOCK)
+__global__ void __launch_bounds__(PC_LEAK_BLOCK, PC_LEAK_MIN_WAVES)
 pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 {
 	constexpr bool EXPLICIT = (MODE == PC_MODE_EXPLICIT);
