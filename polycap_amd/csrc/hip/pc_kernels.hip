@@ -847,7 +847,7 @@ struct pc_hip_ctx {
 	int in_probe = 0;
 	int last_kernel = -1;          /* pc_hip_last_kernel */
 	int last_run_plain = 0;        /* the last run was pc_hip_transmission_run (its counters tell refl_per_launch) */
-	int producer_new_min = 2, producer_new_first = 8;
+	int producer_new_min = 2, producer_new_first = 6;
 	int pool = 0;                  /* 1: single-energy source runs on profiles of up to 1024 points use the per-wave photon pool in LDS (pc_pool_kernel.h).
 	                                * Was the default up to v14 (+6 %); since flights take 5.5 steps instead of 8.8 the exchanges with the pool cost more
 	                                * than its fuller phases save (26.3 ms against 23.3 ms for the one-photon-per-lane kernel) */

@@ -28,6 +28,13 @@
 #endif
 #define PC3_FIELDS 11         /* x, y, dx, dy, dz, ex, ey, ez, kn, (slot, attempt), (qr, bnd) */
 #define PC3_RETRY 64          /* retry requests waiting per tracing wave */
+#ifndef PC3_DONE_RING
+#define PC3_DONE_RING 1       /* finished photons go back to the launching wave, which finalises them 64 at a time (exit window,
+                               * exit record, sums) and keeps the next attempt of the failed ones as its own request; 0: the tracing
+                               * waves finalise and file retry requests */
+#endif
+#define PC3_DCAP 16           /* finished photons waiting per tracing wave */
+#define PC3_DFIELDS 13        /* P, d, e (9), dtravel, weight, (slot, attempt), (reflections, return code) */
 #define PC3_MAX_POLLS 4000000
 #define PC3_MAX_OUTSTANDING (PC3_CONSUMERS*(PC_WAVE + PC3_CAP) + 20)
 #define PC3_MIN_REFL 4.0      /* option "producer" = -1: reflections of transmitted photons per launch from which this kernel is used */
@@ -60,7 +67,11 @@ pc_trace_producer_kernel(pc_kargs a)
 	__shared__ double lds[6*PC3_PITCH];
 	__shared__ pc_marg4 ldsg[PC3_PITCH];
 	__shared__ double l_ring[PC3_MAXCONS*PC3_FIELDS*PC3_CAP];
+#if PC3_DONE_RING
+	__shared__ double l_done[PC3_MAXCONS*PC3_DFIELDS*PC3_DCAP];
+#else
 	__shared__ unsigned long long l_retry[PC3_MAXCONS*PC3_RETRY];
+#endif
 	__shared__ unsigned long long l_req[PC_WAVE];      /* the launching wave's requests, one per lane: (slot << 24 | attempt) + 1, 0 = none */
 	__shared__ pc3_ctrl ctl;
 	const int npts = a.pm.nmax + 1;
@@ -102,6 +113,99 @@ pc_trace_producer_kernel(pc_kargs a)
 		unsigned int f_att = have ? (unsigned int)((rq - 1ull) & 0xffffffull) : 0u;
 		{
 			if (polls > PC3_MAX_POLLS) { if (lane == 0) atomicAdd(&ctl.failed, 1u); return 3; }
+#if PC3_DONE_RING
+			/* finished photons of the tracing waves, ring by ring, into the lanes that hold no request: finalised here, 64 at a
+			 * time (src/polycap-source.c:758-777, 900-923); a failed one becomes this lane's request for the slot's next attempt */
+			{
+				int fin = 0;
+				double gPx = 0., gPy = 0., gPz = 0., gdx = 0., gdy = 0., gdz = 1., gex = 0., gey = 0., gez = 0., gdt = 0., gw = 0.;
+				long long g_slot = 0;
+				unsigned int g_att = 0;
+				int g_irefl = 0, g_rc = 0;
+#pragma unroll 1
+				for (int c = 0; c < PC3_CONSUMERS; c++) {
+					const unsigned long long mFree = __ballot(!have && !fin);
+					if (mFree == 0ull) break;
+					const unsigned int rh = ctl.r_head[c], rt = pc3_load(&ctl.r_tail[c]);
+					int n = (int)(rt - rh);
+					const int nfree = __popcll(mFree);
+					if (n > nfree) n = nfree;
+					if (n > 0) {
+						const int rk = __popcll(mFree & below);
+						if (!have && !fin && rk < n) {
+							const double *q = l_done + (size_t)c*(PC3_DFIELDS*PC3_DCAP) + ((rh + (unsigned)rk) % PC3_DCAP);
+							gPx = q[0*PC3_DCAP]; gPy = q[1*PC3_DCAP]; gPz = q[2*PC3_DCAP];
+							gdx = q[3*PC3_DCAP]; gdy = q[4*PC3_DCAP]; gdz = q[5*PC3_DCAP];
+							gex = q[6*PC3_DCAP]; gey = q[7*PC3_DCAP]; gez = q[8*PC3_DCAP];
+							gdt = q[9*PC3_DCAP]; gw = q[10*PC3_DCAP];
+							const unsigned long long w0 = (unsigned long long)__double_as_longlong(q[11*PC3_DCAP]);
+							const unsigned long long w1 = (unsigned long long)__double_as_longlong(q[12*PC3_DCAP]);
+							g_slot = (long long)(w0 >> 24); g_att = (unsigned int)(w0 & 0xffffffull);
+							g_irefl = (int)(w1 >> 8); g_rc = (int)(w1 & 0xffull) - 2;
+							fin = 1;
+						}
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						if (lane == 0) pc3_store(&ctl.r_head[c], rh + (unsigned)n);
+					}
+				}
+				const unsigned long long mFin = __ballot(fin);
+				if (mFin) {
+					polls = 0;
+					int f_exit = 0, f_nt = 0, f_fail = 0;
+					unsigned long long f_w = 0;
+					if (fin) {
+						int ok = 0;
+						if (g_rc == 0) f_nt = 1;
+						else if (g_rc == 1) {
+							pc_photon<1> fp;
+							fp.Px = gPx; fp.Py = gPy; fp.Pz = gPz; fp.dx = gdx; fp.dy = gdy; fp.dz = gdz;
+							ok = pc_in_exit_window(Pm, fp);
+						}
+						if (ok) {
+							f_exit = 1;
+							f_w = (unsigned long long)(gw * PC_FIX_SCALE);
+							if (a.keep_images) {
+								double *r = a.img + g_slot*ss;
+								const double cosalpha0 = __longlong_as_double((long long)__hip_atomic_load((unsigned long long *)(r + PC_F_EEVX*fs),
+								                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+								a.img_w[g_slot*ws] = gw;
+								double t = (Pm.z_end - gPz) / gdz;
+								double ex = gPx + gdx*t, ey = gPy + gdy*t, ez = gPz + gdz*t;
+								r[PC_F_EXITX*fs] = ex; r[PC_F_EXITY*fs] = ey; r[PC_F_EXITZ*fs] = ez;
+								r[PC_F_EDIRX*fs] = gdx; r[PC_F_EDIRY*fs] = gdy;
+								const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
+								double tx = gex*c_ae + gdx*c_be, ty = gey*c_ae + gdy*c_be, tz = gez*c_ae + gdz*c_be;
+								pc_norm3(tx, ty, tz);
+								r[PC_F_EEVX*fs] = round(tx); r[PC_F_EEVY*fs] = round(ty);
+								((long long *)r)[PC_F_NREFL*fs] = g_irefl;
+								double lx = ex - gPx, ly = ey - gPy, lz = Pm.z_end - gPz;
+								r[PC_F_DTRAVEL*fs] = gdt + sqrt(lx*lx + ly*ly + lz*lz);
+							}
+						} else if (g_att + 1 >= a.max_attempts) {
+							f_fail = 1;
+							if (a.keep_images) { a.img_w[g_slot*ws] = 0.; a.img[g_slot*ss + PC_F_EEVX*fs] = 0.; }
+						} else {
+							f_slot = g_slot; f_att = g_att + 1; have = 1;
+						}
+					}
+					u_not_trans += (unsigned long long)__popcll(__ballot(f_nt));
+					u_failed += (unsigned long long)__popcll(__ballot(f_fail));
+					const unsigned long long mX = __ballot(f_exit);
+					const int nfin = __popcll(mX) + __popcll(__ballot(f_fail));
+					if (nfin > 0 && lane == 0) atomicSub(&ctl.outstanding, (unsigned int)nfin);
+					if (mX) {
+						u_exit += (unsigned long long)__popcll(mX);
+						u_irefl += pc_wave_sum_u64((unsigned long long)(f_exit ? g_irefl : 0));
+						const unsigned long long s_low = pc_wave_sum_u64(f_w & 0xffffffffull), s_high = pc_wave_sum_u64(f_w >> 32);
+						const unsigned long long lo = s_low + (s_high << 32);
+						const unsigned long long hi = (s_high >> 32) + ((lo < s_low) ? 1ull : 0ull);
+						const unsigned long long old = u_acc_lo;
+						u_acc_lo = old + lo;
+						u_acc_hi += hi + ((u_acc_lo < old) ? 1ull : 0ull);
+					}
+				}
+			}
+#else
 			/* retry requests of the tracing waves, ring by ring */
 #pragma unroll 1
 			for (int c = 0; c < PC3_CONSUMERS; c++) {
@@ -123,6 +227,7 @@ pc_trace_producer_kernel(pc_kargs a)
 					if (lane == 0) pc3_store(&ctl.r_head[c], rh + (unsigned)n);
 				}
 			}
+#endif
 			/* fresh slots for the lanes that are still without a request -- while the slots in flight stay below what the
 			 * lanes and the rings of launched photons hold (PC3_MAX_OUTSTANDING): with more, retry requests could fill every
 			 * retry ring while every tracing lane waits to file one and every launching lane holds one -- nobody could move */
@@ -269,7 +374,11 @@ pc_trace_producer_kernel(pc_kargs a)
 		/* ================================================================ a tracing wave */
 		const int c = wave - 1;
 		double *ring = l_ring + (size_t)c*(PC3_FIELDS*PC3_CAP);
+#if PC3_DONE_RING
+		double *dring = l_done + (size_t)c*(PC3_DFIELDS*PC3_DCAP);
+#else
 		unsigned long long *retry = l_retry + c*PC3_RETRY;
+#endif
 		pc_photon<1> ph;
 		ph.wmem = nullptr; ph.wstride = 1; ph.wset = 0; ph.rc = 0; ph.qr = 0; ph.first = 0; ph.lv = 0; ph.bnd = 0; ph.i = 0; ph.irefl = 0;
 		ph.Px = ph.Py = ph.Pz = ph.dx = ph.dy = ph.dz = ph.ex = ph.ey = ph.ez = ph.dtravel = ph.C0 = 0.; ph.w[0] = 0.;
@@ -321,6 +430,30 @@ pc_trace_producer_kernel(pc_kargs a)
 			} else if (nN > 0) {
 				/* ---------------- NEW: finalise finished photons, pop launched ones */
 				st_new += 1; st_new_l += (unsigned)nN;
+#if PC3_DONE_RING
+				{
+					/* finished photons go to the launching wave (as many as its ring takes; the others wait for the next NEW phase) */
+					const unsigned long long mD = __ballot(state == LS_DONE);
+					if (mD) {
+						const int room = PC3_DCAP - (int)(r_tail - pc3_load(&ctl.r_head[c]));
+						const int rk = __popcll(mD & below);
+						if (state == LS_DONE && rk < room) {
+							double *q = dring + ((r_tail + (unsigned)rk) % PC3_DCAP);
+							q[0*PC3_DCAP] = ph.Px; q[1*PC3_DCAP] = ph.Py; q[2*PC3_DCAP] = ph.Pz;
+							q[3*PC3_DCAP] = ph.dx; q[4*PC3_DCAP] = ph.dy; q[5*PC3_DCAP] = ph.dz;
+							q[6*PC3_DCAP] = ph.ex; q[7*PC3_DCAP] = ph.ey; q[8*PC3_DCAP] = ph.ez;
+							q[9*PC3_DCAP] = ph.dtravel; q[10*PC3_DCAP] = ph.w[0];
+							q[11*PC3_DCAP] = __longlong_as_double((long long)(((unsigned long long)slot << 24) | (unsigned long long)(attempt & 0xffffffu)));
+							q[12*PC3_DCAP] = __longlong_as_double((long long)(((unsigned long long)(unsigned int)ph.irefl << 8) | (unsigned long long)((ph.rc + 2) & 0xff)));
+							state = LS_NEED_SLOT;
+						}
+						const int k = __popcll(mD);
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						r_tail += (unsigned)(k < room ? k : room);
+						if (lane == 0) pc3_store(&ctl.r_tail[c], r_tail);
+					}
+				}
+#else
 				int f_exit = 0, f_not_trans = 0, f_failed = 0, want_retry = 0, f_finished = 0;
 				unsigned int f_irefl = 0;
 				unsigned long long f_w = 0;
@@ -388,6 +521,7 @@ pc_trace_producer_kernel(pc_kargs a)
 					const int nfin = __popcll(__ballot(f_finished));
 					if (nfin > 0 && lane == 0) atomicSub(&ctl.outstanding, (unsigned int)nfin);
 				}
+#endif
 				{
 					/* ---------------- pop launched photons */
 					const unsigned long long mQ = __ballot(state == LS_NEED_SLOT);
@@ -421,6 +555,7 @@ pc_trace_producer_kernel(pc_kargs a)
 						if (lane == 0) pc3_store(&ctl.q_head[c], q_head);
 					}
 				}
+#if !PC3_DONE_RING
 				u_not_trans += (unsigned long long)__popcll(__ballot(f_not_trans));
 				u_failed += (unsigned long long)__popcll(__ballot(f_failed));
 				const unsigned long long mX = __ballot(f_exit);
@@ -434,6 +569,7 @@ pc_trace_producer_kernel(pc_kargs a)
 					u_acc_lo = old + lo;
 					u_acc_hi += hi + ((u_acc_lo < old) ? 1ull : 0ull);
 				}
+#endif
 			} else {
 				/* lanes wait for launched photons and nothing else can run */
 				if (pc3_load(&ctl.failed)) break;
@@ -453,8 +589,8 @@ pc_trace_producer_kernel(pc_kargs a)
 			atomicAdd(&a.totals->phase[0], st_march); atomicAdd(&a.totals->phase[1], st_march_l);
 			atomicAdd(&a.totals->phase[2], st_event); atomicAdd(&a.totals->phase[3], st_event_l);
 			atomicAdd(&a.totals->phase[4], st_new); atomicAdd(&a.totals->phase[5], st_new_l);
-			pc_atomic_add128(a.sumw, u_acc_lo, u_acc_hi);
 		}
+		if (u_acc_lo | u_acc_hi) pc_atomic_add128(a.sumw, u_acc_lo, u_acc_hi);
 		if (wave == 0) atomicAdd(&a.totals->phase[6], st_batches);
 	}
 	__syncthreads();

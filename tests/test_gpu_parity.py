@@ -481,9 +481,10 @@ def test_pool_and_producer_kernels_are_bit_identical(pa, oracle):
                 assert a["failed_slots"] > 0 and not done.all()
 
 
-def test_kernel_choice_by_photon_lifetime(pa, oracle):
+def test_kernel_choice_by_photon_lifetime(pa, oracle, monkeypatch):
     """Option "producer" = -1 (default): a context's first big run is preceded by a small probe with the default kernel; the
     launching-wave kernel then traces optics whose photons reflect often (xos1) and the default kernel the others."""
+    monkeypatch.delenv("POLYCAP_PRODUCER", raising=False)      # the suite may run with the kernel forced: this test is about the choice
     _, _, prob, _ = make_pair(oracle, "xos1", source=(2000., 0.2065, 0.2065, 0., 0., 0., 0., 0.0))
     with pa.TraceContext(prob) as ctx:
         small = ctx.transmission(5, 0, 100_000)
