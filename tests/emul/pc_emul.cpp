@@ -243,7 +243,7 @@ int emul_transmission(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int
 /* Analysis aid (scripts/analysis/flight_stats.py): how the march steps of a run distribute over flights.  hist[256]: flights
  * by number of march steps (last bin: >= 255); steps_by[8]: steps that advanced by 1 / PC_L1 / PC_L2 segments, probes that
  * failed at stride PC_L2 / PC_L1 (the stride is lowered), steps that ended in an EVENT, first-segment steps, flights. */
-static int64_t dbg_adv1_lvcap, dbg_adv1_end;
+static int64_t dbg_adv1_lvcap, dbg_adv1_end, dbg_first_flight;
 int emul_flight_stats(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int64_t n_slots, int64_t *hist, int64_t *steps_by)
 {
 	Emul E;
@@ -271,6 +271,7 @@ int emul_flight_stats(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int
 						        (double)(knf*g.md1*(g.r2 + knf*g.md1) + pc_bits_as_float(g.mb12 & 0xffff0000u)), (double)(knf*g.md2*(g.r2 + knf*g.md2) + pc_bits_as_float(g.mb12 << 16)), (double)g.md1, (double)g.r2, (double)knf, ph.i, ph.lv, st);
 					}
 					in_flight++;
+					if (ph.irefl == 0) dbg_first_flight++;
 					if (first) steps_by[6]++;
 					else if (st == PC_ST_MARCH) {
 						const int adv = ph.i - i0;
@@ -292,7 +293,7 @@ int emul_flight_stats(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int
 			if (ph.rc == 1 && pc_in_exit_window(E.t.pm, ph)) break;
 		}
 	}
-	if (getenv("PC_FS_DEBUG")) fprintf(stderr, "adv1 with stride cap > 0: %lld, adv1 near the end of the profile: %lld\n", (long long)dbg_adv1_lvcap, (long long)dbg_adv1_end);
+	if (getenv("PC_FS_DEBUG")) fprintf(stderr, "adv1 with stride cap > 0: %lld, adv1 near the end of the profile: %lld, steps before the first reflection: %lld\n", (long long)dbg_adv1_lvcap, (long long)dbg_adv1_end, (long long)dbg_first_flight);
 	return 0;
 }
 
