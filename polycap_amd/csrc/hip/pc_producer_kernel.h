@@ -4,15 +4,20 @@
  * entrance tests in one NEW phase: ~1280 VALU instructions that run with 16 of 64 lanes on xos1 (13 % of the kernel), and
  * the finished lanes idle until it runs (another ~13 %).  Doing the launches 64 at a time inside the tracing wave does not
  * work: the sampling code next to a live photon does not fit into 128 registers (profiles/r02/queue_kernel_experiment.txt).
- * Here wave 0 of every 512-thread workgroup does nothing but launch: it takes (slot, attempt) requests -- fresh slots from
- * the work counter, next attempts from the tracing waves -- samples the source and runs the entrance tests for 64 of them at
- * a time (what polycap_source_get_photon and the head of polycap_photon_launch do) and hands the entered photons to the
- * seven tracing waves through single-producer / single-consumer rings in LDS.  A tracing wave's NEW phase only finalises
- * finished photons and pops launched ones.  A photon's result depends on (seed, slot, attempt) only and the totals are exact
- * integers, so the output is bit-identical to pc_trace_kernel's.
+ * Here wave 0 of the 1024-thread workgroup (one per CU) traces nothing.  It takes (slot, attempt) requests -- fresh slots from
+ * the work counter, or the next attempt of a slot whose photon failed -- samples the source and runs the entrance tests for
+ * 64 of them at a time (what polycap_source_get_photon and the head of polycap_photon_launch do) and hands the entered
+ * photons to the 15 tracing waves through single-producer / single-consumer rings in LDS; finished photons come back through
+ * rings of the same kind and are finalised by it, again 64 at a time (exit window, exit record, exact sums:
+ * src/polycap-source.c:758-777, 900-923); an absorbed photon or one that missed the exit window becomes the lane's request for
+ * the slot's next attempt.  A tracing wave's NEW phase is a push and a pop.  A photon's result depends on (seed, slot,
+ * attempt) only and the totals are exact integers, so the output is bit-identical to pc_trace_kernel's (tests/test_gpu_parity.py,
+ * scripts/analysis/check_option.py, scripts/analysis/soak_producer.py).
  *
- * The launching wave ends the run (flag `done`); its own waits are bounded (PC3_MAX_POLLS consecutive polls without progress:
- * it then marks the run failed), and a tracing wave with nothing to trace leaves on either flag. */
+ * The launching wave ends the run (flag `done`: work counter exhausted, no slot in flight); its own waits are bounded
+ * (PC3_MAX_POLLS consecutive polls without progress: it then marks the run failed), and a tracing wave with nothing to trace
+ * leaves on either flag.  The slots in flight are capped (PC3_MAX_OUTSTANDING) below the number at which every ring could be
+ * full while every lane waits to push: there is always a wave that can move. */
 #ifndef PC_PRODUCER_KERNEL_H
 #define PC_PRODUCER_KERNEL_H
 
@@ -27,12 +32,6 @@
 #define PC3_CAP 28            /* launched photons waiting per tracing wave */
 #endif
 #define PC3_FIELDS 11         /* x, y, dx, dy, dz, ex, ey, ez, kn, (slot, attempt), (qr, bnd) */
-#define PC3_RETRY 64          /* retry requests waiting per tracing wave */
-#ifndef PC3_DONE_RING
-#define PC3_DONE_RING 1       /* finished photons go back to the launching wave, which finalises them 64 at a time (exit window,
-                               * exit record, sums) and keeps the next attempt of the failed ones as its own request; 0: the tracing
-                               * waves finalise and file retry requests */
-#endif
 #define PC3_DCAP 16           /* finished photons waiting per tracing wave */
 #define PC3_DFIELDS 13        /* P, d, e (9), dtravel, weight, (slot, attempt), (reflections, return code) */
 #define PC3_MAX_POLLS 4000000
@@ -44,7 +43,7 @@
 
 struct pc3_ctrl {
 	unsigned int q_head[16], q_tail[16];      /* rings of launched photons: tail written by the producer, head by the consumer */
-	unsigned int r_head[16], r_tail[16];      /* rings of retry requests: tail written by the consumer, head by the producer */
+	unsigned int r_head[16], r_tail[16];      /* rings of finished photons: tail written by the consumer, head by the producer */
 	unsigned int outstanding;               /* slots taken from the work counter and not finished yet */
 	unsigned int done;                      /* set by the producer when nothing is left to launch and nothing is in flight */
 	unsigned int failed;                    /* a wave gave up waiting */
@@ -67,11 +66,7 @@ pc_trace_producer_kernel(pc_kargs a)
 	__shared__ double lds[6*PC3_PITCH];
 	__shared__ pc_marg4 ldsg[PC3_PITCH];
 	__shared__ double l_ring[PC3_MAXCONS*PC3_FIELDS*PC3_CAP];
-#if PC3_DONE_RING
 	__shared__ double l_done[PC3_MAXCONS*PC3_DFIELDS*PC3_DCAP];
-#else
-	__shared__ unsigned long long l_retry[PC3_MAXCONS*PC3_RETRY];
-#endif
 	__shared__ unsigned long long l_req[PC_WAVE];      /* the launching wave's requests, one per lane: (slot << 24 | attempt) + 1, 0 = none */
 	__shared__ pc3_ctrl ctl;
 	const int npts = a.pm.nmax + 1;
@@ -113,7 +108,6 @@ pc_trace_producer_kernel(pc_kargs a)
 		unsigned int f_att = have ? (unsigned int)((rq - 1ull) & 0xffffffull) : 0u;
 		{
 			if (polls > PC3_MAX_POLLS) { if (lane == 0) atomicAdd(&ctl.failed, 1u); return 3; }
-#if PC3_DONE_RING
 			/* finished photons of the tracing waves, ring by ring, into the lanes that hold no request: finalised here, 64 at a
 			 * time (src/polycap-source.c:758-777, 900-923); a failed one becomes this lane's request for the slot's next attempt */
 			{
@@ -205,29 +199,6 @@ pc_trace_producer_kernel(pc_kargs a)
 					}
 				}
 			}
-#else
-			/* retry requests of the tracing waves, ring by ring */
-#pragma unroll 1
-			for (int c = 0; c < PC3_CONSUMERS; c++) {
-				const unsigned long long mFree = __ballot(!have);
-				if (mFree == 0ull) break;
-				const unsigned int rh = ctl.r_head[c], rt = pc3_load(&ctl.r_tail[c]);
-				int n = (int)(rt - rh);
-				const int nfree = __popcll(mFree);
-				if (n > nfree) n = nfree;
-				if (n > 0) {
-					const int rk = __popcll(mFree & below);
-					if (!have && rk < n) {
-						const unsigned long long w = l_retry[c*PC3_RETRY + ((rh + (unsigned)rk) % PC3_RETRY)];
-						f_slot = (long long)(w >> 24);
-						f_att = (unsigned int)(w & 0xffffffull);
-						have = 1;
-					}
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-					if (lane == 0) pc3_store(&ctl.r_head[c], rh + (unsigned)n);
-				}
-			}
-#endif
 			/* fresh slots for the lanes that are still without a request -- while the slots in flight stay below what the
 			 * lanes and the rings of launched photons hold (PC3_MAX_OUTSTANDING): with more, retry requests could fill every
 			 * retry ring while every tracing lane waits to file one and every launching lane holds one -- nobody could move */
@@ -374,11 +345,7 @@ pc_trace_producer_kernel(pc_kargs a)
 		/* ================================================================ a tracing wave */
 		const int c = wave - 1;
 		double *ring = l_ring + (size_t)c*(PC3_FIELDS*PC3_CAP);
-#if PC3_DONE_RING
 		double *dring = l_done + (size_t)c*(PC3_DFIELDS*PC3_DCAP);
-#else
-		unsigned long long *retry = l_retry + c*PC3_RETRY;
-#endif
 		pc_photon<1> ph;
 		ph.wmem = nullptr; ph.wstride = 1; ph.wset = 0; ph.rc = 0; ph.qr = 0; ph.first = 0; ph.lv = 0; ph.bnd = 0; ph.i = 0; ph.irefl = 0;
 		ph.Px = ph.Py = ph.Pz = ph.dx = ph.dy = ph.dz = ph.ex = ph.ey = ph.ez = ph.dtravel = ph.C0 = 0.; ph.w[0] = 0.;
@@ -430,7 +397,6 @@ pc_trace_producer_kernel(pc_kargs a)
 			} else if (nN > 0) {
 				/* ---------------- NEW: finalise finished photons, pop launched ones */
 				st_new += 1; st_new_l += (unsigned)nN;
-#if PC3_DONE_RING
 				{
 					/* finished photons go to the launching wave (as many as its ring takes; the others wait for the next NEW phase) */
 					const unsigned long long mD = __ballot(state == LS_DONE);
@@ -453,75 +419,6 @@ pc_trace_producer_kernel(pc_kargs a)
 						if (lane == 0) pc3_store(&ctl.r_tail[c], r_tail);
 					}
 				}
-#else
-				int f_exit = 0, f_not_trans = 0, f_failed = 0, want_retry = 0, f_finished = 0;
-				unsigned int f_irefl = 0;
-				unsigned long long f_w = 0;
-				if (state == LS_DONE) {
-					/* src/polycap-source.c:758-777 (a photon that missed the entrance never gets here: the launching wave counts it) */
-					const int rc = ph.rc;
-					int ok = 0;
-					if (rc == 0) f_not_trans = 1;
-					else if (rc == 1) ok = pc_in_exit_window(Pm, ph);
-					if (ok) {
-						f_exit = 1; f_finished = 1;
-						f_irefl = (unsigned int)ph.irefl;
-						const double w = ph.w[0];
-						f_w = (unsigned long long)(w * PC_FIX_SCALE);
-						if (a.keep_images) {
-							/* src/polycap-source.c:900-923; cos(alpha) of the start vectors was left in the record by the launch */
-							double *r = a.img + slot*ss;
-							const double cosalpha0 = __longlong_as_double((long long)__hip_atomic_load((unsigned long long *)(r + PC_F_EEVX*fs),
-							                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-							a.img_w[slot*ws] = w;
-							double t = (Pm.z_end - ph.Pz) / ph.dz;
-							double ex = ph.Px + ph.dx*t, ey = ph.Py + ph.dy*t, ez = ph.Pz + ph.dz*t;
-							r[PC_F_EXITX*fs] = ex; r[PC_F_EXITY*fs] = ey; r[PC_F_EXITZ*fs] = ez;
-							r[PC_F_EDIRX*fs] = ph.dx; r[PC_F_EDIRY*fs] = ph.dy;
-							const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
-							double tx = ph.ex*c_ae + ph.dx*c_be, ty = ph.ey*c_ae + ph.dy*c_be, tz = ph.ez*c_ae + ph.dz*c_be;
-							pc_norm3(tx, ty, tz);
-							r[PC_F_EEVX*fs] = round(tx); r[PC_F_EEVY*fs] = round(ty);
-							((long long *)r)[PC_F_NREFL*fs] = ph.irefl;
-							double lx = ex - ph.Px, ly = ey - ph.Py, lz = Pm.z_end - ph.Pz;
-							r[PC_F_DTRAVEL*fs] = ph.dtravel + sqrt(lx*lx + ly*ly + lz*lz);
-						}
-						state = LS_NEED_SLOT;
-					} else {
-						if (attempt + 1 >= a.max_attempts) {
-							f_failed = 1; f_finished = 1;
-							if (a.keep_images) { a.img_w[slot*ws] = 0.; a.img[slot*ss + PC_F_EEVX*fs] = 0.; }
-							state = LS_NEED_SLOT;
-						} else {
-							want_retry = 1;          /* the slot's next attempt goes to the launching wave */
-						}
-					}
-				}
-				{
-					/* retry requests: as many as the ring takes; the others come back in the next NEW phase as they are (their
-					 * not-transmitted count is taken only when the request is) */
-					const unsigned long long mR = __ballot(want_retry);
-					int taken = 0;
-					if (mR) {
-						const int room = PC3_RETRY - (int)(r_tail - pc3_load(&ctl.r_head[c]));
-						const int rk = __popcll(mR & below);
-						if (want_retry && rk < room) {
-							retry[(r_tail + (unsigned)rk) % PC3_RETRY] = ((unsigned long long)slot << 24) | (unsigned long long)((attempt + 1) & 0xffffffu);
-							state = LS_NEED_SLOT;
-							taken = 1;
-						}
-						const int k = __popcll(mR);
-						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-						r_tail += (unsigned)(k < room ? k : room);
-						if (lane == 0) pc3_store(&ctl.r_tail[c], r_tail);
-					}
-					if (want_retry && !taken) f_not_trans = 0;
-				}
-				{
-					const int nfin = __popcll(__ballot(f_finished));
-					if (nfin > 0 && lane == 0) atomicSub(&ctl.outstanding, (unsigned int)nfin);
-				}
-#endif
 				{
 					/* ---------------- pop launched photons */
 					const unsigned long long mQ = __ballot(state == LS_NEED_SLOT);
@@ -555,21 +452,6 @@ pc_trace_producer_kernel(pc_kargs a)
 						if (lane == 0) pc3_store(&ctl.q_head[c], q_head);
 					}
 				}
-#if !PC3_DONE_RING
-				u_not_trans += (unsigned long long)__popcll(__ballot(f_not_trans));
-				u_failed += (unsigned long long)__popcll(__ballot(f_failed));
-				const unsigned long long mX = __ballot(f_exit);
-				if (mX) {
-					u_exit += (unsigned long long)__popcll(mX);
-					u_irefl += pc_wave_sum_u64((unsigned long long)f_irefl);
-					const unsigned long long s_low = pc_wave_sum_u64(f_w & 0xffffffffull), s_high = pc_wave_sum_u64(f_w >> 32);
-					const unsigned long long lo = s_low + (s_high << 32);
-					const unsigned long long hi = (s_high >> 32) + ((lo < s_low) ? 1ull : 0ull);
-					const unsigned long long old = u_acc_lo;
-					u_acc_lo = old + lo;
-					u_acc_hi += hi + ((u_acc_lo < old) ? 1ull : 0ull);
-				}
-#endif
 			} else {
 				/* lanes wait for launched photons and nothing else can run */
 				if (pc3_load(&ctl.failed)) break;
