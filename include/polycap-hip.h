@@ -176,7 +176,7 @@ POLYCAP_EXTERN int pc_hip_group_totals(pc_hip_group *group, int reduce, double *
 POLYCAP_EXTERN int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6]);
 /* Which kernel traced the last source run: 0 one photon per lane (pc_trace_kernel), 1 LDS photon pool (option "pool"),
  * 2 launching wave per workgroup (option "producer"; by default chosen when the photons of the context's last run made at
- * least 4 reflections per launch -- a first run of 2e6 slots or more is preceded by a 32768-slot probe).  -1: none yet. */
+ * least 4 segment visits (reflections, mostly; absorbed photons included) per launch -- a first run of 2e6 slots or more is preceded by a 32768-slot probe).  -1: none yet. */
 POLYCAP_EXTERN int pc_hip_last_kernel(pc_hip_ctx *ctx);
 
 /* efficiency formula of src/polycap-source.c:1066-1076 from (summed) totals */

@@ -842,7 +842,7 @@ struct pc_hip_ctx {
 	int producer = -1;             /* single-energy source runs with a launching wave per workgroup (pc_producer_kernel.h): 1 always, 0 never,
 	                                * -1 when photons live long enough for one launching wave per CU to keep up (refl_per_launch, below):
 	                                * -5 % on xos1 and ellip_l9, but 2.3x slower on cone.inp, whose photons hardly reflect */
-	double refl_per_launch = -1.;  /* reflections of transmitted photons per launch in the last source run of this context; < 0: not known.
+	double refl_per_launch = -1.;  /* EVENT visits (reflections, mostly) per launch in the last source run of this context; < 0: not known.
 	                                * A big first run is preceded by a probe of 32768 slots (results unused) */
 	int in_probe = 0;
 	int last_kernel = -1;          /* pc_hip_last_kernel */
@@ -1592,7 +1592,8 @@ int pc_hip_transmission_totals(pc_hip_ctx *ctx, double *sum_weights, int64_t cou
 	if (counters)
 		for (int k = 0; k < 6; k++) counters[k] = (int64_t)t->counters[k];
 	if (t->counters[5] > 0 && ctx->last_run_plain)
-		ctx->refl_per_launch = (double)t->counters[3] / (double)t->counters[5];     /* what the next run chooses its kernel by */
+		ctx->refl_per_launch = (double)t->phase[3] / (double)t->counters[5];        /* segment visits (reflections, mostly) per launch,
+		                                                                              * absorbed photons included: what the next run chooses its kernel by */
 	for (size_t e = 0; e < ne; e++) {
 		if (sum_weights) sum_weights[e] = pc_hip_fixed_to_double(sw[2*e], sw[2*e+1]);
 		if (sumw_fixed) { sumw_fixed[2*e] = sw[2*e]; sumw_fixed[2*e+1] = sw[2*e+1]; }

@@ -36,7 +36,8 @@
 #define PC3_DFIELDS 13        /* P, d, e (9), dtravel, weight, (slot, attempt), (reflections, return code) */
 #define PC3_MAX_POLLS 4000000
 #define PC3_MAX_OUTSTANDING (PC3_CONSUMERS*(PC_WAVE + PC3_CAP) + 20)
-#define PC3_MIN_REFL 4.0      /* option "producer" = -1: reflections of transmitted photons per launch from which this kernel is used */
+#define PC3_MIN_REFL 4.0      /* option "producer" = -1: reflections per launch from which this kernel is used (xos1 at 10-30 keV: 26-12,
+                               * always 10-16 % faster; cone.inp: 0.3, 2x slower; scripts/analysis/producer_crossover.py) */
 #ifndef PC3_SLEEP
 #define PC3_SLEEP 127          /* the launching wave waits for room in the rings 90 % of the time: long naps (8128 clocks) */
 #endif
