@@ -673,7 +673,13 @@ PC_HD int pc_reflect_geom(const pc_photon<NE> &ph, double nx, double ny, double 
 
 /* Fresnel reflectivity rtot (polycap_refl_polar, src/polycap-capil.c:497-545) and roughness factor r_rough (:626-627) of
  * one energy.  Returns -1 on the reference's error exits, else 0. */
-PC_HD int pc_fresnel(const pc_energy_const &ec, const pc_refl_geom &g, double &rtot, double &r_rough)
+/* FORM 0: csq from (t, u = |wi|/(2t)) -- one more division, what single-energy runs use (their kernels are bound by
+ * registers: the other form costs them 2-5 %).  FORM 1: rtot is a ratio of products that are homogeneous in (csr, csi, cos):
+ * everything is carried multiplied by 2t, so that 2t*t = |w| + |wr| and 2t*u = |wi| need neither the division nor a second
+ * use of the root -- what runs with several energies use (one fp64 division less per energy and reflection: 6-11 % of
+ * their kernels).  The two differ in the last bits; which one a run uses depends on its number of energies only. */
+template <int FORM>
+PC_HD int pc_fresnel_f(const pc_energy_const &ec, const pc_refl_geom &g, double &rtot, double &r_rough)
 {
 	if (ec.valid == 0.) return -1;
 	const double ct = g.alfa;
@@ -683,17 +689,26 @@ PC_HD int pc_fresnel(const pc_energy_const &ec, const pc_refl_geom &g, double &r
 	/* principal complex square root without cancellation: t = sqrt((|w|+|wr|)/2), u = |wi|/(2t);
 	 * (csr, |csi|) = (t, u) for wr >= 0 and (u, t) for wr < 0; the imaginary part takes the sign of wi */
 	double mag = sqrt(fma(wr, wr, wi*wi));
-	double tt = sqrt(0.5*(mag + fabs(wr)));
-	double uu = (tt > 0.) ? fabs(wi)/(2.*tt) : 0.;
-	double csr = (wr >= 0.) ? tt : uu;
-	double csi = copysign((wr >= 0.) ? uu : tt, wi);
+	double q2 = mag + fabs(wr);                  /* 2 t^2 */
+	double tt = sqrt(0.5*q2);
+	double big, small, cts;
+	if (FORM == 0) {
+		big = tt;
+		small = (tt > 0.) ? fabs(wi)/(2.*tt) : 0.;
+		cts = ct;
+	} else {
+		const double sc = (tt > 0.) ? 2.*tt : 1.0;   /* the common factor (w == 0: csq = 0, q2 = |wi| = 0, any factor will do) */
+		big = q2; small = fabs(wi); cts = ct*sc;
+	}
+	double csr = (wr >= 0.) ? big : small;
+	double csi = copysign((wr >= 0.) ? small : big, wi);
 	/* r_s = (cos - n*csq)/(cos + n*csq)   (:507-510) */
 	double tr = fma(ec.n_re, csr, -ec.n_im*csi);
 	double ti = fma(ec.n_re, csi, ec.n_im*csr);
-	double nr = ct - tr, dr = ct + tr;
+	double nr = cts - tr, dr = cts + tr;
 	double Ns = fma(nr, nr, ti*ti), Ds = fma(dr, dr, ti*ti);
 	/* r_p = (csq - n*cos)/(csq + n*cos)   (:512-515) */
-	double ur = ec.n_re*ct, ui = ec.n_im*ct;
+	double ur = ec.n_re*cts, ui = ec.n_im*cts;
 	double pr = csr - ur, pi_ = csi - ui, er = csr + ur, ei = csi + ui;
 	double Np = fma(pr, pr, pi_*pi_), Dp = fma(er, er, ei*ei);
 	/* rtot = R_s frac_s + R_p frac_p = (es2 Ns Dp + ep2 Np Ds) / (sd2 Ds Dp): one division */
@@ -704,14 +719,26 @@ PC_HD int pc_fresnel(const pc_energy_const &ec, const pc_refl_geom &g, double &r
 	return 0;
 }
 
+/* `single`: the run has one energy (FORM 0), else FORM 1 */
+PC_HD int pc_fresnel(const pc_energy_const &ec, const pc_refl_geom &g, double &rtot, double &r_rough, int single)
+{
+	return single ? pc_fresnel_f<0>(ec, g, rtot, r_rough) : pc_fresnel_f<1>(ec, g, rtot, r_rough);
+}
+
 /* one energy of src/polycap-capil.c:625-645: w *= rtot * r_rough.  Returns -1 on the reference's error exits,
  * else 1 when the new weight is still >= 1e-4, else 0. */
-PC_HD int pc_reflect_energy(const pc_energy_const &ec, const pc_refl_geom &g, double &w)
+template <int FORM>
+PC_HD int pc_reflect_energy_f(const pc_energy_const &ec, const pc_refl_geom &g, double &w)
 {
 	double rtot, r_rough;
-	if (pc_fresnel(ec, g, rtot, r_rough) < 0) return -1;
+	if (pc_fresnel_f<FORM>(ec, g, rtot, r_rough) < 0) return -1;
 	w = w * rtot * r_rough;
 	return (w >= 1.e-4) ? 1 : 0;
+}
+
+PC_HD int pc_reflect_energy(const pc_energy_const &ec, const pc_refl_geom &g, double &w, int single)
+{
+	return single ? pc_reflect_energy_f<0>(ec, g, w) : pc_reflect_energy_f<1>(ec, g, w);
 }
 
 /* whole reflection for one lane: geometry, all energies in order (stopping at the first error like the reference),
@@ -726,7 +753,7 @@ PC_HD int pc_reflect(const pc_params &Pm, const pc_energy_const *EC, pc_photon<N
 	const int ne = (NE > 0) ? NE : Pm.n_energies;
 	for (int e = 0; e < ne; e++) {
 		double we = (NE > 0) ? ph.w[NE > 0 ? e : 0] : (ph.wset ? ph.wmem[e*ph.wstride] : 1.0);
-		int r = pc_reflect_energy(EC[e], g, we);
+		int r = (NE == 1) ? pc_reflect_energy_f<0>(EC[e], g, we) : ((NE > 1) ? pc_reflect_energy_f<1>(EC[e], g, we) : pc_reflect_energy(EC[e], g, we, ne == 1));
 		if (r < 0) return -1;
 		if (NE > 0) ph.w[NE > 0 ? e : 0] = we; else ph.wmem[e*ph.wstride] = we;
 		keep |= r;

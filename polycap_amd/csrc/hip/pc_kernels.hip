@@ -247,7 +247,7 @@ pc_trace_kernel(pc_kargs a)
 							gp.st2 = fma(-gp.alfa, gp.alfa, 1.0);
 							gp.ep2 = gp.sd2 - gp.es2;
 							if (!dead) {
-								const int rr = pc_reflect_energy(ec, gp, wv[k]);
+								const int rr = pc_reflect_energy_f<1>(ec, gp, wv[k]);
 								if (rr < 0) { badbits |= 1u << r; dead = 1; }
 								if (rr > 0) keepbits |= 1u << r;
 							}
@@ -372,7 +372,7 @@ pc_trace_kernel(pc_kargs a)
 								gp.es2 = __shfl(g.es2, from, PC_WAVE); gp.ep2 = __shfl(g.ep2, from, PC_WAVE); gp.sd2 = __shfl(g.sd2, from, PC_WAVE);
 								int bad = 0, keep = 0;
 								if (srcv[j] >= 0 && e < ne) {
-									int r = pc_reflect_energy(ec, gp, wv[j]);
+									int r = pc_reflect_energy_f<1>(ec, gp, wv[j]);
 									a.wscratch[(wave_gtid0 + srcv[j])*(long long)ne + e] = wv[j];
 									bad = (r < 0);
 									keep = (r > 0);
@@ -414,7 +414,7 @@ pc_trace_kernel(pc_kargs a)
 									ec.n_re = ecs[e]; ec.n_im = ecs[ne + e];
 									ec.ninv2_re = ecs[2*ne + e]; ec.ninv2_im = ecs[3*ne + e];
 									ec.rough_c = ecs[4*ne + e]; ec.valid = ecs[5*ne + e];
-									int r = pc_reflect_energy(ec, gp, wv[k]);
+									int r = pc_reflect_energy_f<1>(ec, gp, wv[k]);
 									wp[e] = wv[k];
 									bad |= (r < 0);
 									keep |= (r > 0);

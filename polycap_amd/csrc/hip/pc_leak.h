@@ -657,7 +657,7 @@ PC_HD void pc_leak_unit_other(const pc_tables &T, const pc_params &Pm, pc_leak_l
 			wl = cx.frames + (long)(L.lvl + 1)*fstride + PC_LF_HDR;
 			for (int e = 0; e < ne; e++) {
 				double rtot, r_rough;
-				if (pc_fresnel(cx.ec[e], L.g, rtot, r_rough) < 0) { r = -1; break; }
+				if (pc_fresnel(cx.ec[e], L.g, rtot, r_rough, cx.ne == 1) < 0) { r = -1; break; }
 				wl[e] = (1.-rtot * r_rough) * w[e] * exp(-1.*dtr*cx.amu[e]);
 				if (wl[e] >= 1.e-4) leak_flag = 1;
 				w[e] = w[e] * rtot * r_rough;
