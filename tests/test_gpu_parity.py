@@ -481,6 +481,25 @@ def test_pool_and_producer_kernels_are_bit_identical(pa, oracle):
                 assert a["failed_slots"] > 0 and not done.all()
 
 
+def test_batched_reflections_equal_the_immediate_sweep(pa):
+    """Beyond 32 energies a source run pushes its reflections into LDS and sweeps a photon's weights once per four of them,
+    flying on as a survivor meanwhile (option batch_reflections, default on): counters, exact sums, every exit weight and
+    every image plane equal those of the immediate sweep, on the C3 and the C5 deck."""
+    import os
+    from tests.conftest import EXAMPLE
+    for deck, sig, n in (("xos1", None, 40000), ("ellip_l9", 5.0, 30000)):
+        prob = pa.problem_from_inp(os.path.join(EXAMPLE, deck + ".inp"), sig_rough=sig)
+        assert prob.n_energies == 291
+        out = []
+        with pa.TraceContext(prob) as ctx:
+            for b in (0, 1):
+                ctx.set_option("batch_reflections", b)
+                out.append(ctx.transmission(77, 0, n, keep_images=True))
+        a, b = out
+        assert np.array_equal(a["counters"][:4], b["counters"][:4]) and np.array_equal(a["sumw_fixed"], b["sumw_fixed"]), deck
+        assert np.array_equal(a["exit_weights"], b["exit_weights"]) and np.array_equal(a["images"], b["images"], equal_nan=True), deck
+
+
 def test_kernel_choice_by_photon_lifetime(pa, oracle, monkeypatch):
     """Option "producer" = -1 (default): a context's first big run is preceded by a small probe with the default kernel; the
     launching-wave kernel then traces optics whose photons reflect often (xos1) and the default kernel the others."""
