@@ -11,6 +11,6 @@ There is no CPU implementation of the trace path in this package.
 """
 from ._cabi import Problem, lib  # noqa: F401
 from .hip import TraceContext, TraceGroup, HipError, device_count, efficiencies, fixed_to_double, IMG_FIELDS  # noqa: F401
-from .decks import problem_from_inp, optical_constants  # noqa: F401
+from .decks import problem_from_inp, optical_constants, optical_constants_provider  # noqa: F401
 
 __version__ = "1.2"

@@ -189,17 +189,39 @@ void pc_set_hip_error(polycap_error **error, const char *caller, int status)
 }
 
 /* Returns the HIP context -- or, with a device list, the group of contexts -- for (description, energies[, source]);
- * rebuilt only when one of them changed.  The device is POLYCAP_HIP_DEVICE (default 0).  There is no CPU fallback:
+ * rebuilt only when one of them, or the device, changed.  device < 0: POLYCAP_HIP_DEVICE (default 0).  There is no CPU fallback:
  * failure is reported to the caller. */
-static int pc_cache_prepare(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
-	const polycap_source *source, int n_devices, const int *devices, const char *caller, polycap_error **error)
+/* The table provider is announced once per (composition, energy grid): key = FNV-1a over both */
+static int pc_warned_before(const polycap_description *d, size_t n_energies, const double *energies)
 {
+	static uint64_t seen[256];
+	static int n_seen = 0;
+	uint64_t h = 1469598103934665603ull;
+	const unsigned char *parts[4] = { (const unsigned char *)d->iz, (const unsigned char *)d->wi, (const unsigned char *)&d->density, (const unsigned char *)energies };
+	const size_t lens[4] = { sizeof(int)*d->nelem, sizeof(double)*d->nelem, sizeof(double), sizeof(double)*n_energies };
+	for (int k = 0; k < 4; k++)
+		for (size_t i = 0; i < lens[k]; i++) { h ^= parts[k][i]; h *= 1099511628211ull; }
+	for (int k = 0; k < n_seen; k++)
+		if (seen[k] == h) return 1;
+	if (n_seen < 256) seen[n_seen++] = h;
+	return 0;
+}
+
+static int pc_cache_prepare(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
+	const polycap_source *source, int device, int n_devices, const int *devices, const char *caller, polycap_error **error)
+{
+	if (n_devices == 0 && device < 0) {
+		device = 0;
+		const char *env = getenv("POLYCAP_HIP_DEVICE");
+		if (env != NULL && *env != '\0')
+			device = atoi(env);
+	}
 	double src[8] = {1., 1., 1., 0., 0., 0., 0., 0.};
 	if (source != NULL) {
 		src[0] = source->d_source; src[1] = source->src_x; src[2] = source->src_y; src[3] = source->src_sigx;
 		src[4] = source->src_sigy; src[5] = source->src_shiftx; src[6] = source->src_shifty; src[7] = source->hor_pol;
 	}
-	const int same_target = (n_devices == 0) ? (c->ctx != NULL)
+	const int same_target = (n_devices == 0) ? (c->ctx != NULL && c->device == device)
 		: (c->group != NULL && c->n_devices == n_devices && memcmp(c->devices, devices, sizeof(int)*(size_t)n_devices) == 0);
 	if (same_target && c->n_energies == n_energies && memcmp(c->energies, energies, sizeof(double)*n_energies) == 0 &&
 	    c->has_source == (source != NULL) && memcmp(c->src, src, sizeof(src)) == 0)
@@ -222,19 +244,19 @@ static int pc_cache_prepare(pc_ctx_cache *c, polycap_description *description, s
 		pc_ctx_cache_clear(c);
 		return -1;
 	}
+	c->synthetic = synthetic;
 	if (synthetic) {
 		/* The reference takes these constants from xraylib.  Without libxrl the built-in table is exact only where the
-		 * reference's own tests pin it (10 keV; 40 and 80 keV are fits to its leak answers): say so once, on stderr, unless
-		 * the caller chose the table explicitly (POLYCAP_OPTCONST=builtin). */
-		static int warned = 0;
+		 * reference's own tests pin it (10 keV; 40 and 80 keV are fits to its leak answers): say so on stderr, once per
+		 * (composition, energy grid), unless the caller chose the table explicitly (POLYCAP_OPTCONST=builtin).  The flag also
+		 * travels with the result (pc_transmission_efficiencies_synthetic). */
 		const char *choice = getenv("POLYCAP_OPTCONST");
-		if (!warned && !(choice != NULL && strcmp(choice, "builtin") == 0)) {
+		if (!(choice != NULL && strcmp(choice, "builtin") == 0) && !pc_warned_before(description, n_energies, energies)) {
 			double lo = energies[0], hi = energies[0];
 			for (size_t i = 1; i < n_energies; i++) {
 				if (energies[i] < lo) lo = energies[i];
 				if (energies[i] > hi) hi = energies[i];
 			}
-			warned = 1;
 			fprintf(stderr, "polycap (%s): xraylib (libxrl) not found; optical constants for %g-%g keV come from %s, "
 				"approximate away from 10 keV.  Install xraylib for the reference's values, or set POLYCAP_OPTCONST=builtin to accept the table.\n",
 				caller, lo, hi, pc_optconst_provider());
@@ -250,11 +272,8 @@ static int pc_cache_prepare(pc_ctx_cache *c, polycap_description *description, s
 	p.src_shiftx = src[5]; p.src_shifty = src[6]; p.hor_pol = src[7];
 	int status;
 	if (n_devices == 0) {
-		int device = 0;
-		const char *env = getenv("POLYCAP_HIP_DEVICE");
-		if (env != NULL && *env != '\0')
-			device = atoi(env);
 		status = pc_hip_ctx_create(&p, device, &c->ctx);
+		c->device = device;
 	} else {
 		status = pc_hip_group_create(&p, n_devices, devices, &c->group);
 		c->n_devices = n_devices;
@@ -273,12 +292,18 @@ static int pc_cache_prepare(pc_ctx_cache *c, polycap_description *description, s
 	return 0;
 }
 
+pc_hip_ctx *pc_ctx_for_device(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
+	const polycap_source *source, int device, const char *caller, polycap_error **error)
+{
+	if (pc_cache_prepare(c, description, n_energies, energies, source, device, 0, NULL, caller, error) != 0)
+		return NULL;
+	return c->ctx;
+}
+
 pc_hip_ctx *pc_ctx_for(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
 	const polycap_source *source, const char *caller, polycap_error **error)
 {
-	if (pc_cache_prepare(c, description, n_energies, energies, source, 0, NULL, caller, error) != 0)
-		return NULL;
-	return c->ctx;
+	return pc_ctx_for_device(c, description, n_energies, energies, source, -1, caller, error);
 }
 
 pc_hip_group *pc_group_for(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
@@ -288,7 +313,7 @@ pc_hip_group *pc_group_for(pc_ctx_cache *c, polycap_description *description, si
 		polycap_set_error(error, POLYCAP_ERROR_INVALID_ARGUMENT, "%s: POLYCAP_HIP_DEVICES must name between 1 and 64 devices", caller);
 		return NULL;
 	}
-	if (pc_cache_prepare(c, description, n_energies, energies, source, n_devices, devices, caller, error) != 0)
+	if (pc_cache_prepare(c, description, n_energies, energies, source, -1, n_devices, devices, caller, error) != 0)
 		return NULL;
 	return c->group;
 }

@@ -27,8 +27,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* xraylib >= 4.0 entry points: double f(int Z, double E, xrl_error **error) and double AtomicWeight(int Z, xrl_error **error).
+ * The reference passes NULL for the error pointer (src/polycap-photon.c:87-88) and so never notices a failed lookup (xraylib then
+ * returns 0); this build passes a real pointer and turns a reported error into POLYCAP_ERROR_RUNTIME. */
 typedef double (*xrl_cs_fn)(int, double, void **);
 typedef double (*xrl_aw_fn)(int, void **);
+typedef void (*xrl_err_free_fn)(void *);
+struct pc_xrl_error { int code; char *message; };   /* xraylib.h: typedef struct { xrl_error_code code; char *message; } xrl_error */
 
 static struct {
 	int probed;
@@ -36,34 +41,87 @@ static struct {
 	xrl_cs_fn cs_total;
 	xrl_cs_fn fi;
 	xrl_aw_fn atomic_weight;
+	xrl_err_free_fn error_free;     /* optional */
+	char name[256];
 } g_xrl;
 
-static int pc_xrl_available(void)
+/* POLYCAP_OPTCONST=builtin: the caller accepts the built-in tables (read on every call, so a process can change its mind) */
+static int pc_builtin_chosen(void)
+{
+	const char *env = getenv("POLYCAP_OPTCONST");
+	return env != NULL && strcmp(env, "builtin") == 0;
+}
+
+static int pc_xrl_try(const char *name)
+{
+	void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+	if (h == NULL)
+		return 0;
+	g_xrl.cs_total = (xrl_cs_fn)dlsym(h, "CS_Total");
+	g_xrl.fi = (xrl_cs_fn)dlsym(h, "Fi");
+	g_xrl.atomic_weight = (xrl_aw_fn)dlsym(h, "AtomicWeight");
+	g_xrl.error_free = (xrl_err_free_fn)dlsym(h, "xrl_error_free");
+	if (g_xrl.cs_total == NULL || g_xrl.fi == NULL || g_xrl.atomic_weight == NULL) {
+		dlclose(h);
+		return 0;
+	}
+	g_xrl.handle = h;
+	snprintf(g_xrl.name, sizeof(g_xrl.name), "%s", name);
+	return 1;
+}
+
+/* the library is looked for once per process: POLYCAP_XRL_LIBRARY (a path), then the sonames of xraylib 4.x on the loader's path */
+static int pc_xrl_loaded(void)
 {
 	if (!g_xrl.probed) {
 		g_xrl.probed = 1;
-		const char *env = getenv("POLYCAP_OPTCONST");
-		if (env != NULL && strcmp(env, "builtin") == 0)
-			return 0;
+		const char *path = getenv("POLYCAP_XRL_LIBRARY");
+		if (path != NULL && *path != '\0')
+			pc_xrl_try(path);
 		static const char *names[] = { "libxrl.so.11", "libxrl.so.7", "libxrl.so", NULL };
 		for (int i = 0; names[i] != NULL && g_xrl.handle == NULL; i++)
-			g_xrl.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
-		if (g_xrl.handle != NULL) {
-			g_xrl.cs_total = (xrl_cs_fn)dlsym(g_xrl.handle, "CS_Total");
-			g_xrl.fi = (xrl_cs_fn)dlsym(g_xrl.handle, "Fi");
-			g_xrl.atomic_weight = (xrl_aw_fn)dlsym(g_xrl.handle, "AtomicWeight");
-			if (g_xrl.cs_total == NULL || g_xrl.fi == NULL || g_xrl.atomic_weight == NULL) {
-				dlclose(g_xrl.handle);
-				g_xrl.handle = NULL;
-			}
-		}
+			pc_xrl_try(names[i]);
 	}
 	return g_xrl.handle != NULL;
+}
+
+static int pc_xrl_available(void)
+{
+	return !pc_builtin_chosen() && pc_xrl_loaded();
 }
 
 const char *pc_optconst_provider(void)
 {
 	return pc_xrl_available() ? "xraylib" : "built-in tables (B O Na Mg Al Si K Ca Ba Pb; O/Si pinned at 10, 40, 80 keV)";
+}
+
+/* the shared object behind provider "xraylib", or "" */
+const char *pc_optconst_library(void)
+{
+	return pc_xrl_available() ? g_xrl.name : "";
+}
+
+/* one xraylib lookup; a reported error -> POLYCAP_ERROR_RUNTIME, returns -1 */
+static int pc_xrl_lookup(int which, int z, double e, double *out, polycap_error **error)
+{
+	void *xerr = NULL;
+	static const char *fn[] = { "CS_Total", "Fi", "AtomicWeight" };
+	if (which == 0) *out = g_xrl.cs_total(z, e, &xerr);
+	else if (which == 1) *out = g_xrl.fi(z, e, &xerr);
+	else *out = g_xrl.atomic_weight(z, &xerr);
+	if (xerr != NULL) {
+		const char *msg = ((const struct pc_xrl_error *)xerr)->message;
+		polycap_set_error(error, POLYCAP_ERROR_RUNTIME, "polycap_photon_scatf: xraylib %s(Z=%d, E=%g keV) failed: %s",
+			fn[which], z, e, msg != NULL ? msg : "(no message)");
+		if (g_xrl.error_free != NULL)
+			g_xrl.error_free(xerr);
+		return -1;
+	}
+	if (!isfinite(*out)) {
+		polycap_set_error(error, POLYCAP_ERROR_RUNTIME, "polycap_photon_scatf: xraylib %s(Z=%d, E=%g keV) returned a non-finite value", fn[which], z, e);
+		return -1;
+	}
+	return 0;
 }
 
 /* ---- built-in tables ----
@@ -115,6 +173,11 @@ static const double g_mu_Mg[] = PC_TAB(9.225e2, 4.530e2, 5.444e3, 4.004e3, 1.932
 static const double g_E_Al[]  = PC_TAB(1, 1.5, 1.5596, 1.5596, 2, 3, 4, 5, 6, 8, 10, 15, 20, 30, 40, 50, 60, 80, 100);
 static const double g_mu_Al[] = PC_TAB(1.185e3, 4.022e2, 3.621e2, 3.957e3, 2.263e3, 7.880e2, 3.605e2, 1.934e2, 1.153e2, 5.033e1, 2.623e1, 7.955, 3.441,
                                        1.128, 5.685e-1, 3.681e-1, 2.778e-1, 2.018e-1, 1.704e-1);
+/* What the NIST grid holds where the fits above replace it (pc_optconst_unfitted, scripts/optconst_selfcheck.py) */
+#define PC_MUSI_40KEV_TABLE 7.012e-1
+#define PC_MUSI_80KEV_TABLE 2.228e-1
+#define PC_FSI_10KEV_TABLE 0.206
+#define PC_FSI_40KEV_TABLE 0.02
 static const double g_E_Si[]  = PC_TAB(1, 1.5, 1.8389, 1.8389, 2, 3, 4, 5, 6, 8, 10, 15, 20, 30, 40, 50, 60, 80, 100);
 static const double g_mu_Si[] = PC_TAB(1.570e3, 5.355e2, 3.092e2, 3.192e3, 2.777e3, 9.784e2, 4.529e2, 2.450e2, 1.470e2, 6.468e1, 3.389e1, 1.034e1, 4.464,
                                        1.436, PC_MUSI_40KEV, 4.385e-1, 3.207e-1, PC_MUSI_80KEV, 1.835e-1);
@@ -198,14 +261,38 @@ static double pc_semilog(const double *x, const double *y, int n, double e)
 	return y[k] + t*(y[k+1] - y[k]);
 }
 
+/* POLYCAP_OPTCONST_UNFITTED=1 (diagnostics, scripts/optconst_selfcheck.py): the Si entries that are fitted to the reference's
+ * known answers (mu/rho at 40 and 80 keV, f' at 10 and 40 keV) and the common O/Si scale take their plain table values */
+static int pc_unfitted(void)
+{
+	const char *env = getenv("POLYCAP_OPTCONST_UNFITTED");
+	return env != NULL && *env == '1';
+}
+
 static int pc_builtin(int z, double e, double *cs, double *fi, double *aw)
 {
 	for (size_t k = 0; k < sizeof(g_elem)/sizeof(g_elem[0]); k++) {
 		const struct pc_elem_table *t = &g_elem[k];
 		if (t->z != z)
 			continue;
-		*cs = t->mu_scale * pc_loglog(t->e, t->mu, t->n, e);
-		*fi = pc_semilog(t->ef, t->fp, t->nf, e);
+		if (z == 14 && pc_unfitted()) {
+			double mu[PC_LEN(g_mu_Si)], fp[PC_LEN(g_fp_Si)];
+			memcpy(mu, g_mu_Si, sizeof(mu));
+			memcpy(fp, g_fp_Si, sizeof(fp));
+			for (int i = 0; i < t->n; i++) {
+				if (t->e[i] == 40.) mu[i] = PC_MUSI_40KEV_TABLE;
+				if (t->e[i] == 80.) mu[i] = PC_MUSI_80KEV_TABLE;
+			}
+			for (int i = 0; i < t->nf; i++) {
+				if (t->ef[i] == 10.) fp[i] = PC_FSI_10KEV_TABLE;
+				if (t->ef[i] == 40.) fp[i] = PC_FSI_40KEV_TABLE;
+			}
+			*cs = pc_loglog(t->e, mu, t->n, e);
+			*fi = pc_semilog(t->ef, fp, t->nf, e);
+		} else {
+			*cs = ((z == 8 && pc_unfitted()) ? 1.0 : t->mu_scale) * pc_loglog(t->e, t->mu, t->n, e);
+			*fi = pc_semilog(t->ef, t->fp, t->nf, e);
+		}
 		*aw = t->aw;
 		return 0;
 	}
@@ -250,15 +337,34 @@ int pc_optconst_scatf(unsigned int nelem, const int *iz, const double *wi, doubl
 	}
 
 	const int use_xrl = pc_xrl_available();
+	int only_o_si = 1;
+	for (unsigned int j = 0; j < nelem; j++)
+		if (iz[j] != 8 && iz[j] != 14) only_o_si = 0;
+	if (!use_xrl && !only_o_si && !pc_builtin_chosen()) {
+		/* The tables of the other glass constituents could not be checked against their sources (see above): they are used only
+		 * when the caller asks for them by name; the O/Si glass of the reference's decks and tests is pinned by its own tests */
+		for (unsigned int j = 0; j < nelem; j++) {
+			double cs, fi, aw;
+			if (iz[j] != 8 && iz[j] != 14 && pc_builtin(iz[j], 10., &cs, &fi, &aw) != 0) {
+				polycap_set_error(error, POLYCAP_ERROR_UNSUPPORTED,
+					"polycap_photon_scatf: no optical constants for Z=%d: xraylib (libxrl) was not found and the built-in tables cover B, O, Na, Mg, Al, Si, K, Ca, Ba and Pb", iz[j]);
+				return -1;
+			}
+		}
+		polycap_set_error_literal(error, POLYCAP_ERROR_UNSUPPORTED,
+			"polycap_photon_scatf: xraylib (libxrl) was not found; the built-in tables for elements other than O and Si are unverified "
+			"approximations and are used only on request: set POLYCAP_OPTCONST=builtin to accept them, or install xraylib");
+		return -1;
+	}
 	int synth = 0;
 	for (size_t i = 0; i < n_energies; i++) {
 		double totmu = 0, sf = 0;
 		for (unsigned int j = 0; j < nelem; j++) {
 			double cs, fi, aw;
 			if (use_xrl) {
-				cs = g_xrl.cs_total(iz[j], energies[i], NULL);
-				fi = g_xrl.fi(iz[j], energies[i], NULL);
-				aw = g_xrl.atomic_weight(iz[j], NULL);
+				if (pc_xrl_lookup(0, iz[j], energies[i], &cs, error) != 0 || pc_xrl_lookup(1, iz[j], energies[i], &fi, error) != 0 ||
+				    pc_xrl_lookup(2, iz[j], energies[i], &aw, error) != 0)
+					return -1;
 			} else if (pc_builtin(iz[j], energies[i], &cs, &fi, &aw) != 0) {
 				polycap_set_error(error, POLYCAP_ERROR_UNSUPPORTED,
 					"polycap_photon_scatf: no optical constants for Z=%d: xraylib (libxrl) was not found and the built-in tables cover B, O, Na, Mg, Al, Si, K, Ca, Ba and Pb", iz[j]);
@@ -269,14 +375,9 @@ int pc_optconst_scatf(unsigned int nelem, const int *iz, const double *wi, doubl
 		}
 		amu[i] = totmu * density;
 		scatf[i] = sf;
-		if (!use_xrl) {
-			/* exact only where the reference's tests pin the O/Si glass: at 10 keV (and, fitted, 40 / 80 keV) */
-			int only_o_si = 1;
-			for (unsigned int j = 0; j < nelem; j++)
-				if (iz[j] != 8 && iz[j] != 14) only_o_si = 0;
-			if (!only_o_si || energies[i] != 10.0)
-				synth = 1;
-		}
+		/* without xraylib: exact only where the reference's tests pin the O/Si glass: at 10 keV (and, fitted, 40 / 80 keV) */
+		if (!use_xrl && (!only_o_si || energies[i] != 10.0 || pc_unfitted()))
+			synth = 1;
 	}
 	if (synthetic != NULL)
 		*synthetic = synth;

@@ -29,6 +29,8 @@ typedef struct {
 	pc_hip_group *group;      /* POLYCAP_HIP_DEVICES: one context per listed device instead of `ctx` */
 	int n_devices;
 	int devices[64];
+	int device;               /* device of `ctx` */
+	int synthetic;            /* the optical constants of this context come from the built-in tables away from their pinned points */
 	size_t n_energies;
 	double *energies;
 	int has_source;
@@ -125,6 +127,7 @@ struct _polycap_transmission_efficiencies {
 	double *efficiencies;
 	struct _polycap_images *images;
 	polycap_source *source;
+	int synthetic_constants;   /* extension: see pc_transmission_efficiencies_synthetic */
 };
 
 /* internal helpers */
@@ -137,6 +140,10 @@ int polycap_photon_within_pc_boundary(double polycap_radius, polycap_vector3 pho
 POLYCAP_EXTERN int pc_optconst_scatf(unsigned int nelem, const int *iz, const double *wi, double density,
 	size_t n_energies, const double *energies, double *amu, double *scatf, int *synthetic, polycap_error **error);
 POLYCAP_EXTERN const char *pc_optconst_provider(void);
+POLYCAP_EXTERN const char *pc_optconst_library(void);
+/* 1 when the efficiencies were computed with optical constants from the built-in tables away from the points the reference's
+ * tests pin (no xraylib on the machine); 0 with xraylib or at the pinned points */
+POLYCAP_EXTERN int pc_transmission_efficiencies_synthetic(const polycap_transmission_efficiencies *efficiencies);
 /* name of the HDF5 shared library bound at run time by the result writer, or "none" */
 POLYCAP_EXTERN const char *pc_hdf5_provider(void);
 
@@ -158,6 +165,9 @@ bool pc_leak_list_copy(polycap_leak **src, int64_t n_src, polycap_leak ***leaks,
 void pc_ctx_cache_clear(pc_ctx_cache *c);
 pc_hip_ctx *pc_ctx_for(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
 	const polycap_source *source, const char *caller, polycap_error **error);
+/* the same on an explicit device (< 0: POLYCAP_HIP_DEVICE, default 0); the cache is keyed on the device too */
+pc_hip_ctx *pc_ctx_for_device(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
+	const polycap_source *source, int device, const char *caller, polycap_error **error);
 /* the same for a device list (POLYCAP_HIP_DEVICES): a group of contexts, one per entry */
 pc_hip_group *pc_group_for(pc_ctx_cache *c, polycap_description *description, size_t n_energies, const double *energies,
 	const polycap_source *source, int n_devices, const int *devices, const char *caller, polycap_error **error);

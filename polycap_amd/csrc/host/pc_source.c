@@ -428,15 +428,9 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 	pc_hip_group *group = NULL;
 	if (n_devices > 0 && !leak_calc)
 		group = pc_group_for(&source->cache, description, ne, source->energies, source, n_devices, devices, "polycap_source_get_transmission_efficiencies", error);
-	else {
-		if (n_devices == 1) {
-			/* a one-entry list selects the device like POLYCAP_HIP_DEVICE */
-			char buf[16];
-			snprintf(buf, sizeof(buf), "%d", devices[0]);
-			setenv("POLYCAP_HIP_DEVICE", buf, 1);
-		}
-		ctx = pc_ctx_for(&source->cache, description, ne, source->energies, source, "polycap_source_get_transmission_efficiencies", error);
-	}
+	else      /* a one-entry list (or the first entry, for a leak run) selects the device; none: POLYCAP_HIP_DEVICE, default 0 */
+		ctx = pc_ctx_for_device(&source->cache, description, ne, source->energies, source, n_devices >= 1 ? devices[0] : -1,
+		                        "polycap_source_get_transmission_efficiencies", error);
 	if (ctx == NULL && group == NULL) {
 		free(sum_weights);
 		polycap_transmission_efficiencies_free(eff);
@@ -513,6 +507,7 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 	printf("iexit: %" PRId64 ", no enter: %" PRId64 ", no trans: %" PRId64 "\n", sum_iexit, sum_not_entered, sum_not_transmitted);
 
 	pc_transeff_finish(eff, sum_weights, counters);
+	eff->synthetic_constants = source->cache.synthetic;
 	if (!keep_images)
 		eff->images->i_exit = 0;     /* no per-photon planes were kept: the exit/start getters report no events */
 	free(sum_weights);

@@ -91,6 +91,11 @@ static void pc_images_free(struct _polycap_images *images)
 	free(images);
 }
 
+int pc_transmission_efficiencies_synthetic(const polycap_transmission_efficiencies *efficiencies)
+{
+	return efficiencies != NULL ? efficiencies->synthetic_constants : 0;
+}
+
 void polycap_transmission_efficiencies_free(polycap_transmission_efficiencies *efficiencies)
 {
 	if (efficiencies == NULL)

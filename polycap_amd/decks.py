@@ -9,13 +9,19 @@ from ._cabi import Problem, ProblemS, c_double_p
 from ._cabi import ErrS as _ErrS
 
 
+# polycap_error codes -> Python exceptions as in the reference's binding (python/polycap.pyx:91-107)
+_EXC = {0: MemoryError, 1: ValueError, 2: IOError, 3: RuntimeError, 4: TypeError, 5: NotImplementedError, 6: RuntimeError}
+
+
 def _raise(L, err, where):
     msg = "%s failed" % where
+    exc = ValueError
     if err:
         e = err.contents
         msg = "%s: [%d] %s" % (where, e.code, e.message.decode() if e.message else "")
+        exc = _EXC.get(e.code, RuntimeError)
         L.polycap_error_free(err)
-    raise ValueError(msg)
+    raise exc(msg)
 
 
 def _protos(L):
@@ -34,7 +40,16 @@ def _protos(L):
                                     c_double_p, c_double_p, C.POINTER(C.c_int), C.POINTER(C.POINTER(_ErrS))]
     L.pc_optconst_scatf.restype = C.c_int
     L.pc_optconst_provider.restype = C.c_char_p
+    L.pc_optconst_library.restype = C.c_char_p
     L._decks_ready = True
+
+
+def optical_constants_provider():
+    """"xraylib" when a libxrl could be bound (and POLYCAP_OPTCONST is not "builtin"), else a description of the built-in tables."""
+    L = _cabi.lib()
+    _protos(L)
+    p = L.pc_optconst_provider().decode()
+    return "xraylib" if p == "xraylib" else p
 
 
 def optical_constants(iz, wi, density, energies):

@@ -126,7 +126,7 @@ def test_explicit_photons_vs_oracle(pa, oracle):
         # measured on the oracle itself: a 1-ulp input change flips rc or i_refl for 13-15 % of photons; the kernel
         # differs from the oracle by rounding only, so it must stay well below that
         flips = ((o["rc"] != g["rc"]) | (o["i_refl"] != g["i_refl"])).mean()
-        assert flips < 0.10, flips
+        assert flips < 0.06, flips                      # observed 3.9 % (profiles/r02/parity_1e8.json)
         # short trajectories (<= 3 reflections): amplification is still small
         short = (o["rc"] == g["rc"]) & (o["i_refl"] == g["i_refl"]) & (o["i_refl"] <= 3) & np.isin(o["rc"], (0, 1))
         assert short.sum() >= 5
@@ -231,9 +231,9 @@ def test_multi_energy_and_roughness(pa, oracle):
         g = ctx.launch_photons(ph[:, 0:3], ph[:, 3:6], ph[:, 6:9])
         t = ctx.transmission(5, 0, 5000, keep_images=True)
     flips = ((o["rc"] != g["rc"]) | (o["i_refl"] != g["i_refl"])).mean()
-    assert flips < 0.10
+    assert flips < 0.06, flips
     so, sg = o["weights"][o["rc"] == 1].sum(axis=0), g["weights"][g["rc"] == 1].sum(axis=0)
-    assert np.all(np.abs(sg - so) / so < 1.5 / np.sqrt(n))      # the weight spread grows with energy: 1.5 instead of 1.0
+    assert np.all(np.abs(sg - so) / so < 1.0 / np.sqrt(n)), (np.abs(sg - so) / so * np.sqrt(n)).max()
     short = (o["rc"] == g["rc"]) & (o["i_refl"] == g["i_refl"]) & (o["i_refl"] <= 3) & np.isin(o["rc"], (0, 1))
     assert rel(g["weights"][short], o["weights"][short]).max() < 1e-6
     assert np.all(np.diff(t["efficiencies"]) < 0)      # transmission falls with energy
@@ -437,7 +437,8 @@ def test_many_energies_match_the_host_compile(pa, oracle, n_energies):
         assert np.array_equal(g[k], e[k], equal_nan=True), k
     o = oracle.transmission(optic, src, E, A, S, 9, 0, 20000)
     assert t["i_exit"] == 20000
-    assert np.all(np.abs(t["efficiencies"] - o["efficiencies"]) <= 2.5 / np.sqrt(o["i_start"]) * o["efficiencies"] + 1e-12)
+    assert np.all(np.abs(t["efficiencies"] - o["efficiencies"]) <= 1.5 / np.sqrt(o["i_start"]) * o["efficiencies"] + 1e-12), \
+        (np.abs(t["efficiencies"] / o["efficiencies"] - 1.0) * np.sqrt(o["i_start"])).max()
     w = t["exit_weights"]
     assert w.shape == (20000, n_energies) and np.all((w >= 0) & (w <= 1)) and np.all(w.max(axis=1) >= 1e-4)
     # checksum of checksums: the per-slot weights add up to the exact fixed-point totals, energy by energy
@@ -609,7 +610,7 @@ def test_c5_deck_roughness_vs_oracle(pa, oracle):
     optic = oracle.Optic(rough.z, rough.cap, rough.ext, 5.0, rough.n_cap, rough.density)
     o = oracle.transmission(optic, oracle.make_source(*rough.source), rough.energies, rough.amu, rough.scatf, 77, 0, n)
     assert g["i_exit"] == n == o["i_exit"]
-    tol = 3.0 / np.sqrt(o["i_start"])
+    tol = 1.5 / np.sqrt(o["i_start"])
     assert abs(g["i_start"] - o["i_start"]) / o["i_start"] < tol
     lo = E <= 15.0          # beyond, a handful of photons carry the sum and the relative error grows (1 % at 30 keV)
     assert np.all(np.abs(g["efficiencies"] / o["efficiencies"] - 1.0)[lo] < tol)
