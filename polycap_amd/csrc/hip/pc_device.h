@@ -741,6 +741,107 @@ PC_HD int pc_reflect_energy(const pc_energy_const &ec, const pc_refl_geom &g, do
 	return single ? pc_reflect_energy_f<0>(ec, g, w) : pc_reflect_energy_f<1>(ec, g, w);
 }
 
+/* ------------------------------------------------------------------ FORM 2: the sweeps of the any-n_energies kernel
+ * The same reflectivity as FORM 1 (everything carried multiplied by 2t), written for the weight sweeps of runs whose weights
+ * live in memory (more than 8 energies): there the Fresnel arithmetic IS the kernel (75 % of its instructions), and two
+ * correctly rounded fp64 square roots and a division are ~45 of its ~100 instructions per energy and reflection.  On the
+ * device the two roots come from v_rsq_f64 and the quotient from v_rcp_f64 (2^-24, measured: scripts/analysis/fp64_rates.hip)
+ * with one Newton step each (2^-48 ~ 4e-15 relative, no range scaling: the arguments are |w|^2 and 2(|w| + |Re w|) with
+ * |w| >= |Im(1/n^2)| sin^2, far from the ends of the exponent range) -- 14 instructions instead of 45.  The weights then
+ * differ from FORM 0/1 and from the host compile by a few 1e-15 per reflection; the trajectory does not depend on them (only
+ * the rare "no weight >= 1e-4 left" decision does), so the kernel stays photon-for-photon the host compile up to those
+ * decisions.  The host compile evaluates the same expressions with IEEE sqrt and division.  Callers guarantee ec.valid != 0
+ * (runs with an invalid energy keep FORM 1). */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PC_FAST_MATH_DEVICE 1
+#else
+#define PC_FAST_MATH_DEVICE 0
+#endif
+
+/* sqrt(x), x > 0 and normal */
+PC_HD double pc_sqrt_fast(double x)
+{
+#if PC_FAST_MATH_DEVICE
+	const double y = __builtin_amdgcn_rsq(x);
+	const double g = x*y, h = 0.5*y;
+	const double r = fma(-h, g, 0.5);
+	return fma(g, r, g);
+#else
+	return sqrt(x);
+#endif
+}
+
+/* a / b */
+PC_HD double pc_div_fast(double a, double b)
+{
+#if PC_FAST_MATH_DEVICE
+	const double y = __builtin_amdgcn_rcp(b);
+	const double e = fma(-b, y, 1.0);
+	return a*fma(y, e, y);
+#else
+	return a / b;
+#endif
+}
+
+/* exp(x) for x <= 0 (the roughness factor exp(-(c alfa)^2)): 2^k e^r with |r| <= ln2/2 and a degree-11 polynomial, 6e-15 */
+PC_HD double pc_exp_neg_fast(double x)
+{
+#if PC_FAST_MATH_DEVICE
+	const double k = rint(x*1.4426950408889634074);
+	double r = fma(-k, 6.93147180369123816490e-01, x);
+	r = fma(-k, 1.90821492927058770002e-10, r);
+	double p = 2.50521083854417187751e-08;                 /* 1/11! */
+	p = fma(p, r, 2.75573192239858906526e-07);
+	p = fma(p, r, 2.75573192239858906526e-06);
+	p = fma(p, r, 2.48015873015873015873e-05);
+	p = fma(p, r, 1.98412698412698412698e-04);
+	p = fma(p, r, 1.38888888888888888889e-03);
+	p = fma(p, r, 8.33333333333333333333e-03);
+	p = fma(p, r, 4.16666666666666666667e-02);
+	p = fma(p, r, 1.66666666666666666667e-01);
+	p = fma(p, r, 0.5);
+	p = fma(p, r, 1.0);
+	p = fma(p, r, 1.0);
+	return __builtin_amdgcn_ldexp(p, (int)k);                /* underflows to 0 by itself */
+#else
+	return exp(x);
+#endif
+}
+
+/* per-energy constants of FORM 2: n = n_re + i n_im, (1/n)^2 = a_re + i a_im, rough_c; reflection geometry ct = cos(theta)
+ * (>= 0), st2 = sin^2, es2, ep2, sd2 as in pc_refl_geom.  Returns the factor rtot (* r_rough if ROUGH) the weight is multiplied
+ * by; rtot itself goes to `rt` for the caller's range test (the reference rejects rtot < 0 or > 1, :633-637). */
+template <bool ROUGH>
+PC_HD double pc_fresnel_fast(double n_re, double n_im, double a_re, double a_im, double rough_c,
+                             double ct, double st2, double es2, double ep2, double sd2, double &rt)
+{
+	const double wr = fma(-a_re, st2, 1.0);
+	const double wi = -a_im*st2;
+	/* |w|^2, floored far below anything a physical 1/n^2 produces (w == 0 needs Im n == 0 and the exact critical angle): keeps
+	 * the reciprocal square roots finite; the result there is the limit R = 1 to rounding */
+	const double mag2 = fmax(fma(wr, wr, wi*wi), 6.223015277861142e-61 /* 2^-200 */);
+	const double mag = pc_sqrt_fast(mag2);
+	const double q2 = mag + fabs(wr);                        /* 2 t^2 */
+	const double sc = pc_sqrt_fast(q2 + q2);                 /* 2 t */
+	const double cts = ct*sc;
+	const double awi = fabs(wi);
+	const double csr = (wr >= 0.) ? q2 : awi;
+	const double csi = copysign((wr >= 0.) ? awi : q2, wi);
+	const double tr = fma(n_re, csr, -n_im*csi);
+	const double ti = fma(n_re, csi, n_im*csr);
+	const double nr = cts - tr, dr = cts + tr;
+	const double ti2 = ti*ti;
+	const double Ns = fma(nr, nr, ti2), Ds = fma(dr, dr, ti2);
+	const double ur = n_re*cts, ui = n_im*cts;
+	const double pr = csr - ur, pi_ = csi - ui, er = csr + ur, ei = csi + ui;
+	const double Np = fma(pr, pr, pi_*pi_), Dp = fma(er, er, ei*ei);
+	const double rtot = pc_div_fast(fma(es2*Ns, Dp, ep2*Np*Ds), sd2*Ds*Dp);
+	rt = rtot;
+	if (!ROUGH) return rtot;
+	const double c1 = rough_c*ct;
+	return rtot*pc_exp_neg_fast(-c1*c1);
+}
+
 /* whole reflection for one lane: geometry, all energies in order (stopping at the first error like the reference),
  * new electric vector.  Returns 1 keep, 0 absorbed, -1 error. */
 template <int NE>

@@ -25,6 +25,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "polycap-hip.h"
@@ -101,6 +102,7 @@ struct pc_kargs {
 	int lds_ec;                   /* NE == 0: per-energy constants staged in LDS behind the sums (6*n_energies doubles) */
 	int lds_pend;                 /* NE == 0, more than 32 energies: reflections wait in LDS (PC_KB x 3 doubles per lane, behind the
 	                               * constants) and a photon's weights are swept once per PC_KB reflections */
+	int sweep_rough;              /* NE == 0: some energy has a roughness factor (sig_rough != 0): the sweeps evaluate exp(-(c alfa)^2) */
 	int pool_event_min;           /* pool kernel: photons waiting for an EVENT phase that make it run before anything else */
 	int event_march;              /* pool kernel: march steps taken right after an EVENT phase, while the wave is still full of fresh flights */
 	int pool_refill;              /* pool kernel: lanes that must be free before a march burst tops itself up from the pool */
@@ -130,6 +132,19 @@ __device__ __forceinline__ void pc_atomic_add128(unsigned long long *lohi, unsig
 	unsigned long long old = atomicAdd(&lohi[0], lo);
 	unsigned long long carry = (old + lo < old) ? 1ull : 0ull;
 	if (hi + carry) atomicAdd(&lohi[1], hi + carry);
+}
+
+/* one energy of one reflection in the sweeps of the any-n_energies kernel: FORM 2 of pc_device.h (hardware reciprocal
+ * square root / reciprocal + one Newton step).  Same return values as pc_reflect_energy_f. */
+__device__ __forceinline__ int pc_reflect_energy_sweep(const pc_energy_const &ec, const pc_refl_geom &g, double &w, int rough)
+{
+	if (ec.valid == 0.) return -1;
+	double rt;
+	const double f = rough ? pc_fresnel_fast<true>(ec.n_re, ec.n_im, ec.ninv2_re, ec.ninv2_im, ec.rough_c, g.alfa, g.st2, g.es2, g.ep2, g.sd2, rt)
+	                       : pc_fresnel_fast<false>(ec.n_re, ec.n_im, ec.ninv2_re, ec.ninv2_im, 0., g.alfa, g.st2, g.es2, g.ep2, g.sd2, rt);
+	if (rt < 0. || rt > 1.) return -1;                          /* src/polycap-capil.c:633-637 */
+	w = w*f;
+	return (w >= 1.e-4) ? 1 : 0;
 }
 
 /* --------------------------------------------------------------------------- the trace kernel
@@ -213,64 +228,113 @@ pc_trace_kernel(pc_kargs a)
 	 * the reference, and what it did afterwards is dropped (a photon that ends with rc -1/0/1 is swept before it is
 	 * finalised, so nothing speculative is ever counted). */
 	double *const l_pend = (NE == 0 && a.lds_pend) ? (double *)(l_acc + 2*a.pm.n_energies) + 6*a.pm.n_energies : nullptr;
-	auto flush = [&](unsigned long long mF) {
+	/* The sweep is FLAT over (photon, energy) pairs: the photons of the wave whose reflections are due form one list of
+	 * nP x n_energies items, lane l takes items l, l + 64, ...  (291 energies fill 4.55 passes of one photon -- 9 % idle lanes --
+	 * but 12 photons, the usual number after an EVENT phase, fill 54.6 of 55).  Per wave, in LDS behind the waiting reflections:
+	 * map[rank] = lane | n << 8 | wset << 16 of the rank-th photon, and its verdict: vcnt = reflections of the batch after which
+	 * some energy still holds >= 1e-4 (a weight never grows: the count of an energy is its number of leading "keep"s, the
+	 * photon's the maximum), vbad = first reflection whose rtot the reference rejects at some energy (255: none). */
+	unsigned int *const l_map = l_pend ? (unsigned int *)(l_pend + (size_t)blockDim.x*(3*PC_KB)) + (threadIdx.x >> 6)*(3*PC_WAVE) : nullptr;
+	auto flush_as = [&](unsigned long long mF, auto rough_tag) __attribute__((always_inline)) {
+		constexpr bool ROUGH = decltype(rough_tag)::value;
 		const double *ecs = (const double *)(l_acc + 2*a.pm.n_energies);      /* a.lds_pend implies a.lds_ec */
 		const long long wave_gtid0 = gtid - lane;
 		const int wave_t0 = (int)(threadIdx.x - lane);
-		while (mF) {
-			const int p = __ffsll((long long)mF) - 1;
-			mF &= mF - 1ull;
-			const int n = __shfl(npend, p, PC_WAVE);
-			const int wset_p = __shfl(ph.wset, p, PC_WAVE);
-			const double *gq = l_pend + (size_t)(wave_t0 + p)*(3*PC_KB);
-			double *wp = a.wscratch + (wave_gtid0 + p)*(long long)ne;
-			unsigned int badbits = 0, keepbits = 0;
-			for (int e0 = 0; e0 < ne; e0 += PC_WAVE*PC_KE) {
-				double wv[PC_KE];
+		unsigned int *map = l_map, *vcnt = l_map + PC_WAVE, *vbad = l_map + 2*PC_WAVE;
+		const int mine = (int)((mF >> lane) & 1ull);
+		const int rank = __popcll(mF & ((1ull << lane) - 1ull));
+		if (mine) {
+			map[rank] = (unsigned)lane | ((unsigned)npend << 8) | (ph.wset ? 0x10000u : 0u);
+			vcnt[rank] = 0u; vbad[rank] = 255u;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		const int total = __popcll(mF)*ne;
+		int q = 0, e = lane;
+		while (e >= ne) { e -= ne; q++; }
+		/* the next item's weight is fetched while the current one is computed (the rows live in HBM) */
+		unsigned info_n = 0u; double w_n = 1.0;
+		if (lane < total) {
+			info_n = map[q];
+			if (info_n >> 16) w_n = a.wscratch[(wave_gtid0 + (info_n & 255u))*(long long)ne + e];
+		}
+		for (int base = 0; base < total; base += PC_WAVE) {
+			const int act = base + lane < total;
+			const unsigned info = info_n;
+			double w = w_n;
+			const int qc = q, ec_i = e;
+			e += PC_WAVE;
+			while (e >= ne) { e -= ne; q++; }
+			info_n = 0u; w_n = 1.0;
+			if (base + PC_WAVE + lane < total) {
+				info_n = map[q];
+				if (info_n >> 16) w_n = a.wscratch[(wave_gtid0 + (info_n & 255u))*(long long)ne + e];
+			}
+			unsigned cnt = 0u;
+			int n = 0;
+			if (act) {
+				const int p = (int)(info & 255u);
+				n = (int)((info >> 8) & 255u);
+				const double *gq = l_pend + (size_t)(wave_t0 + p)*(3*PC_KB);
+				const double n_re = ecs[ec_i], n_im = ecs[ne + ec_i], a_re = ecs[2*ne + ec_i], a_im = ecs[3*ne + ec_i];
+				const double rgh = ROUGH ? ecs[4*ne + ec_i] : 0.;
+				double rmax = 0., rmin = 0.;
 #pragma unroll
-				for (int k = 0; k < PC_KE; k++) {
-					const int e = e0 + k*PC_WAVE + lane;
-					wv[k] = (wset_p && e < ne) ? wp[e] : 1.0;
-				}
-#pragma unroll
-				for (int k = 0; k < PC_KE; k++) {
-					const int e = e0 + k*PC_WAVE + lane;
-					if (e < ne) {
-						pc_energy_const ec;
-						ec.n_re = ecs[e]; ec.n_im = ecs[ne + e];
-						ec.ninv2_re = ecs[2*ne + e]; ec.ninv2_im = ecs[3*ne + e];
-						ec.rough_c = ecs[4*ne + e]; ec.valid = ecs[5*ne + e];
-						int dead = 0;       /* the reference stops at the first energy that fails; later reflections are moot */
-						for (int r = 0; r < n; r++) {
-							pc_refl_geom gp;
-							gp.alfa = gq[3*r]; gp.es2 = gq[3*r + 1]; gp.sd2 = gq[3*r + 2];
-							gp.st2 = fma(-gp.alfa, gp.alfa, 1.0);
-							gp.ep2 = gp.sd2 - gp.es2;
-							if (!dead) {
-								const int rr = pc_reflect_energy_f<1>(ec, gp, wv[k]);
-								if (rr < 0) { badbits |= 1u << r; dead = 1; }
-								if (rr > 0) keepbits |= 1u << r;
-							}
-						}
-						wp[e] = wv[k];
+				for (int r = 0; r < PC_KB; r++) {
+					if (r < n) {
+						const double ct = gq[3*r], es2 = gq[3*r + 1], sd2 = gq[3*r + 2];
+						double rt;
+						const double f = pc_fresnel_fast<ROUGH>(n_re, n_im, a_re, a_im, rgh, ct, fma(-ct, ct, 1.0), es2, sd2 - es2, sd2, rt);
+						rmax = fmax(rmax, rt); rmin = fmin(rmin, rt);
+						w = w*f;
+						cnt += (w >= 1.e-4) ? 1u : 0u;
 					}
 				}
+				a.wscratch[(wave_gtid0 + p)*(long long)ne + ec_i] = w;
+				if (rmax > 1. || rmin < 0.) {
+					/* never with physical constants: find this energy's first rejected reflection (rtot does not depend on the weight) */
+					unsigned fb = 255u;
+					for (int r = n - 1; r >= 0; r--) {
+						const double ct = gq[3*r], es2 = gq[3*r + 1], sd2 = gq[3*r + 2];
+						double rt;
+						(void)pc_fresnel_fast<false>(n_re, n_im, a_re, a_im, 0., ct, fma(-ct, ct, 1.0), es2, sd2 - es2, sd2, rt);
+						if (rt < 0. || rt > 1.) fb = (unsigned)r;
+					}
+					atomicMin(&vbad[qc], fb);
+				}
 			}
-			/* first waiting reflection that ends the photon: an error at any energy, or no energy left above 1e-4 */
-			int fail = -1, fail_rc = 0;
-			for (int r = n - 1; r >= 0; r--) {
-				const int anybad = __any((badbits >> r) & 1u), anykeep = __any((keepbits >> r) & 1u);
-				if (anybad || !anykeep) { fail = r; fail_rc = anybad ? -1 : 0; }
-			}
-			if (lane == p) {
-				npend = 0;
-				ph.wset = 1;
-				if (fail >= 0) { state = LS_DONE; ph.rc = fail_rc; }
+			/* verdict: nearly always every energy of the pass kept its weight above 1e-4 through the whole batch -- then one
+			 * lane per photon says so; else every lane reports its count */
+			if (__ballot(act && cnt < (unsigned)n) == 0ull) {
+				const int q_left = __shfl_up(qc, 1, PC_WAVE);
+				if (act && (lane == 0 || q_left != qc)) atomicMax(&vcnt[qc], cnt);
+			} else if (act) {
+				atomicMax(&vcnt[qc], cnt);
 			}
 		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		if (mine) {
+			/* first waiting reflection that ends the photon: an error at any energy (rc -1), or no energy left above 1e-4 (rc 0) */
+			const unsigned c = vcnt[rank], b = vbad[rank];
+			const unsigned fail = (c < b) ? c : b;
+			if (fail < (unsigned)npend) { state = LS_DONE; ph.rc = (b <= c) ? -1 : 0; }
+			npend = 0;
+			ph.wset = 1;
+		}
+	};
+	auto flush = [&](unsigned long long mF) __attribute__((always_inline)) {
+		if (a.sweep_rough) flush_as(mF, std::true_type{});
+		else flush_as(mF, std::false_type{});
 	};
 
 	for (;;) {
+		if (NE == 0 && a.lds_pend) {
+			/* weights are swept when a photon's PC_KB places are full, and before a finished photon is finalised (the one place
+			 * the sweep is instantiated: every photon that is due goes into the same flat list) */
+			const unsigned long long mF = __ballot(npend == PC_KB || (state == LS_DONE && npend > 0));
+			if (mF) flush(mF);
+		}
 		const unsigned long long mM = __ballot(state == LS_MARCH);
 		const unsigned long long mE = __ballot(state == LS_EVENT);
 		const unsigned long long mN = __ballot(state == LS_DONE || state == LS_NEED_SLOT || state == LS_START);
@@ -372,7 +436,7 @@ pc_trace_kernel(pc_kargs a)
 								gp.es2 = __shfl(g.es2, from, PC_WAVE); gp.ep2 = __shfl(g.ep2, from, PC_WAVE); gp.sd2 = __shfl(g.sd2, from, PC_WAVE);
 								int bad = 0, keep = 0;
 								if (srcv[j] >= 0 && e < ne) {
-									int r = pc_reflect_energy_f<1>(ec, gp, wv[j]);
+									int r = pc_reflect_energy_sweep(ec, gp, wv[j], a.sweep_rough);
 									a.wscratch[(wave_gtid0 + srcv[j])*(long long)ne + e] = wv[j];
 									bad = (r < 0);
 									keep = (r > 0);
@@ -414,7 +478,7 @@ pc_trace_kernel(pc_kargs a)
 									ec.n_re = ecs[e]; ec.n_im = ecs[ne + e];
 									ec.ninv2_re = ecs[2*ne + e]; ec.ninv2_im = ecs[3*ne + e];
 									ec.rough_c = ecs[4*ne + e]; ec.valid = ecs[5*ne + e];
-									int r = pc_reflect_energy_f<1>(ec, gp, wv[k]);
+									int r = pc_reflect_energy_sweep(ec, gp, wv[k], a.sweep_rough);
 									wp[e] = wv[k];
 									bad |= (r < 0);
 									keep |= (r > 0);
@@ -441,10 +505,6 @@ pc_trace_kernel(pc_kargs a)
 					if (pend == 1) { if (!(NE == 0 && a.lds_pend)) ph.wset = 1; ph.ex = fabs(ph.ex); ph.ey = fabs(ph.ey); ph.ez = fabs(ph.ez); }
 					state = pc_event_post(Pm, ph, h, res);
 				}
-				if (NE == 0 && a.lds_pend) {
-					const unsigned long long mF = __ballot(npend == PC_KB);
-					if (mF) flush(mF);
-				}
 			}
 		} else if (nN > 0 && do_new) {
 			st_new += 1; st_new_l += (unsigned)nN;
@@ -454,10 +514,6 @@ pc_trace_kernel(pc_kargs a)
 			unsigned int f_irefl = 0;
 			unsigned long long f_w = 0;
 			const long long done_slot = slot;
-			if (NE == 0 && a.lds_pend) {
-				const unsigned long long mF = __ballot(state == LS_DONE && npend > 0);
-				if (mF) flush(mF);
-			}
 			if (state == LS_DONE) {
 				const int rc = ph.rc;
 				if (EXPLICIT) {
@@ -947,7 +1003,8 @@ static int pc_launch_one(pc_hip_ctx *ctx, const pc_kargs &a, int grid)
 	/* table pitch: 1024 entries (48 KB of LDS) covers the reference's generated profiles (nmax = 999) and its example decks */
 	const size_t dyn = ((NE != 1 && a.lds_acc) ? 2*(size_t)ctx->host.pm.n_energies*sizeof(unsigned long long) : 0)
 	                 + ((NE == 0 && a.lds_ec) ? 6*(size_t)ctx->host.pm.n_energies*sizeof(double) : 0)
-	                 + ((NE == 0 && a.lds_pend) ? (size_t)(a.total_threads / grid)*3*PC_KB*sizeof(double) : 0);
+	                 + ((NE == 0 && a.lds_pend) ? (size_t)(a.total_threads / grid)*3*PC_KB*sizeof(double)
+	                                              + (size_t)(a.total_threads / grid / PC_WAVE)*3*PC_WAVE*sizeof(unsigned int) : 0);
 	const int block = (int)(a.total_threads / grid);
 	if (ctx->host.pm.nmax + 1 <= 1024)
 		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, 1024>), dim3(grid), dim3(block), dyn, ctx->stream, a);
@@ -986,7 +1043,13 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 	 * 512) leaves room in LDS for the per-energy constants next to the tables and the sums */
 	a.lds_ec = (kne == 0 && a.lds_acc && ctx->lds_ec && ctx->host.pm.nmax + 1 <= 1024 && 64*(size_t)ne <= 28672) ? 1 : 0;
 	/* more than 32 energies: PC_KB reflections per sweep of a photon's weights (their geometry waits in LDS: 96 B per lane) */
-	a.lds_pend = (a.lds_ec && ne > 32 && ctx->batch_reflections && MODE != PC_MODE_EXPLICIT) ? 1 : 0;   /* source runs only: an explicit
+	bool all_valid = true;
+	a.sweep_rough = 0;
+	for (const pc_energy_const &c : ctx->host.ec) {
+		if (c.valid == 0.) all_valid = false;
+		if (c.rough_c != 0.) a.sweep_rough = 1;
+	}
+	a.lds_pend = (a.lds_ec && ne > 32 && ctx->batch_reflections && all_valid && MODE != PC_MODE_EXPLICIT) ? 1 : 0;   /* source runs only: an explicit
 	                                       * photon reports its state at the absorbing reflection, which the speculation overwrites */
 	if constexpr (MODE != PC_MODE_EXPLICIT) {
 		const pc_params &pm = ctx->host.pm;
