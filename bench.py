@@ -216,9 +216,10 @@ def main():
         if world == 1 and not args.no_extras:
             if keep_images:
                 out["wall_incl_copyback"] = wall_incl_copyback(deck, n_local, started / float(args.steps * n_local))
-            out["sweep_291"] = side_workload("xos1", None, None, 1_000_000, dev_index)
+            out["sweep_291"] = side_workload("xos1", None, None, 1_000_000, dev_index, "profiles/r03/ne291_pmc_summary.json")
             out["ellip_l9_rough"] = {"n_energies_1": side_workload("ellip_l9", [10.0], 5.0, 4_000_000, dev_index),
-                                     "n_energies_291": side_workload("ellip_l9", None, 5.0, 500_000, dev_index)}
+                                     "n_energies_291": side_workload("ellip_l9", None, 5.0, 500_000, dev_index,
+                                                                     "profiles/r03/ellip291_pmc_summary.json")}
         if world == 1 and not args.no_extras:
             out["parity_fixture"] = parity_fixture(prob, dev_index)
         if not args.no_cpu_baseline and world == 1:
@@ -255,8 +256,10 @@ def valu_issue(pmc, kernel_ms):
             "source": os.path.relpath(PMC_SUMMARY, ROOT) + " (rocprofv3 --pmc) / HIP-event kernel time of this run"}
 
 
-def side_workload(deck_name, energies, sig_rough, n_slots, dev_index):
-    """started photons/s of another BASELINE configuration's kernel (histogram only, one warm-up + one timed run)"""
+def side_workload(deck_name, energies, sig_rough, n_slots, dev_index, pmc_file=None):
+    """started photons/s of another BASELINE configuration's kernel (histogram only, one warm-up + one timed run).
+    pmc_file: committed rocprofv3 --pmc summary of exactly this workload (scripts/profile_r03.sh + scripts/side_workload.py):
+    its SQ_INSTS_VALU over the kernel time measured here is the VALU issue rate, the resource this kernel is bound by."""
     import polycap_amd
     path = os.path.join(ROOT, "tests", "golden", "example", deck_name + ".inp")
     prob = polycap_amd.problem_from_inp(path, energies=energies, sig_rough=sig_rough)
@@ -266,12 +269,26 @@ def side_workload(deck_name, energies, sig_rough, n_slots, dev_index):
         r = c.transmission(2, 0, n_slots)
         dt = time.perf_counter() - t0
     eff = r["efficiencies"]
-    return {"workload": "example/%s.inp, %d energies%s, %d exit photons, histogram only" %
-                        (deck_name, prob.n_energies, "" if sig_rough is None else ", sig_rough %g A" % sig_rough, n_slots),
-            "started_photons_per_s": r["i_start"] / (r["kernel_ms"] * 1e-3), "kernel_ms": r["kernel_ms"], "wall_ms": dt * 1e3,
-            "n_started": r["i_start"], "n_exit": r["i_exit"], "n_energies": prob.n_energies,
-            "efficiency_first_last": [float(eff[0]), float(eff[-1])],
-            "constants": "synthetic away from 10 keV" if getattr(prob, "synthetic_constants", False) else "pinned"}
+    out = {"workload": "example/%s.inp, %d energies%s, %d exit photons, histogram only" %
+                       (deck_name, prob.n_energies, "" if sig_rough is None else ", sig_rough %g A" % sig_rough, n_slots),
+           "started_photons_per_s": r["i_start"] / (r["kernel_ms"] * 1e-3), "kernel_ms": r["kernel_ms"], "wall_ms": dt * 1e3,
+           "n_started": r["i_start"], "n_exit": r["i_exit"], "n_energies": prob.n_energies,
+           "efficiency_first_last": [float(eff[0]), float(eff[-1])],
+           "constants": "synthetic away from 10 keV" if getattr(prob, "synthetic_constants", False) else "pinned"}
+    if pmc_file is not None:
+        try:
+            with open(os.path.join(ROOT, pmc_file)) as f:
+                pmc = json.load(f)
+            rate = pmc["SQ_INSTS_VALU"] / (r["kernel_ms"] * 1e-3)
+            out["valu_issue"] = {"wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "achieved_per_s": rate,
+                                 "peak_per_s": VALU_ISSUE_PEAK, "frac": rate / VALU_ISSUE_PEAK,
+                                 "lane_utilisation": pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]),
+                                 "wait_share": pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"] if "SQ_WAIT_ANY" in pmc else None,
+                                 "hbm_traffic_bytes_per_launch": (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc else None,
+                                 "source": pmc_file + " (rocprofv3 --pmc of this workload) / HIP-event kernel time of this run"}
+        except Exception:
+            out["valu_issue"] = None
+    return out
 
 
 def wall_incl_copyback(deck, n_photons, started_per_exit):

@@ -88,6 +88,13 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
  *                      is then a copy-engine transfer into the caller's planes, pinned for the duration of the call;
  *                      pc_hip_transmission_records is not available for such a run.  0 (default) = one record per slot,
  *                      turned into planes on the device when pc_hip_transmission_images asks for them
+ *   "compact_images"   with "plane_images": 1 = exit photons are stored in the order in which they leave the optic instead of
+ *                      at the position of their slot -- the photons a wave finalises together are one coalesced run per plane
+ *                      (the reference's order of photons in its arrays is as arbitrary: it is the order in which OpenMP
+ *                      threads with random seeds happen to fill them) -- and the planes are published in blocks of
+ *                      2^"block_shift" positions (default 18) while the kernel runs: pc_hip_transmission_images copies a block
+ *                      as soon as it is complete.  The set of photons is the same as with 0 (default), bit for bit.
+ *   "slot_ids"         compact runs also record which slot sits at which position (pc_hip_transmission_slot_ids)
  *   "batch_reflections" many-energy source runs: sweep a photon's weights once per four reflections (default 1)
  *   "fetch_threads"    host threads of the staging fallback of the image fetch (0 = min(16, cores))
  *   leak runs: "leak_max_depth" (stack frames per lane = walls one photon may cross), "leak_stack_mb" (HBM for those
@@ -128,6 +135,9 @@ POLYCAP_EXTERN int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, in
  * records: [count][PC_HIP_N_PLANES + n_energies]. */
 #define PC_HIP_N_PLANES 17
 POLYCAP_EXTERN int pc_hip_transmission_records(pc_hip_ctx *ctx, int64_t first, int64_t count, double *records);
+/* Slot (relative to slot0 of the last run) of the photon stored at positions [first, first+count) of the image planes:
+ * the identity unless the run was compact ("compact_images" with "slot_ids"). */
+POLYCAP_EXTERN int pc_hip_transmission_slot_ids(pc_hip_ctx *ctx, int64_t first, int64_t count, int64_t *slots);
 
 /* ---- leak_calc = true ("halo" photons): src/polycap-capil.c:610-619, 657-1194, src/polycap-photon.c:171-362, 645-907,
  * src/polycap-source.c:799-879, 925-1032.  Same calls with the fraction of every reflection that is transmitted through

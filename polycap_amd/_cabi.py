@@ -140,6 +140,8 @@ def lib():
     L.pc_hip_transmission_images.restype = C.c_int
     L.pc_hip_transmission_records.argtypes = [C.c_void_p, C.c_int64, C.c_int64, P(C.c_double)]
     L.pc_hip_transmission_records.restype = C.c_int
+    L.pc_hip_transmission_slot_ids.argtypes = [C.c_void_p, C.c_int64, C.c_int64, c_int64_p]
+    L.pc_hip_transmission_slot_ids.restype = C.c_int
     L.pc_hip_phase_stats.argtypes = [C.c_void_p, c_int64_p]
     L.pc_hip_phase_stats.restype = C.c_int
     L.pc_hip_last_kernel.argtypes = [C.c_void_p]

@@ -46,6 +46,9 @@
 #ifndef PC_KB
 #define PC_KB 4                /* reflections of a photon that wait for one sweep of its weights (many-energy kernel) */
 #endif
+#ifndef PC_SWEEP_IL
+#define PC_SWEEP_IL 1          /* (photon, energy) items a lane has in flight together in the flat sweep of the many-energy kernel */
+#endif
 #ifndef PC_CHUNK
 #define PC_CHUNK 128           /* slots a wave takes from the global counter at a time */
 #endif
@@ -97,6 +100,19 @@ struct pc_kargs {
 	                               * [slot][n_energies], img_ws = n_energies */
 	double *img_w;
 	long long img_ss, img_fs, img_ws;
+	/* Compact image store (option "compact_images", planes only): an exit photon takes the next free position of the run's
+	 * planes instead of the position of its slot -- the photons a wave finalises together are written as one coalesced run per
+	 * plane -- and the blocks of 2^blk_shift positions are published as they fill (the copy engine fetches behind the kernel).
+	 * The order of the photons in the planes is then the order of completion; img_ids, when asked for, says which slot sits
+	 * where. */
+	unsigned long long *img_cursor;   /* next free position, or NULL: a photon is stored at its slot */
+	long long *img_ids;               /* slot of position p (option "slot_ids"), or NULL */
+	unsigned int *blk_done;           /* per block: positions written so far */
+	unsigned int *blk_flag;           /* per block, host-visible: complete */
+	int blk_shift;
+	long long img_n;                  /* positions of the launch: its slots */
+	double *lane_start;               /* compact store in the kernels that launch in the tracing lane: the 8 start fields of the
+	                                   * lane's photon wait here, one 64-byte line per lane, until the photon has left the optic */
 	int new_threshold;
 	int lds_acc;                  /* NE == 0: accumulate weight sums in LDS (2*n_energies u64 of dynamic LDS) */
 	int lds_ec;                   /* NE == 0: per-energy constants staged in LDS behind the sums (6*n_energies doubles) */
@@ -114,6 +130,85 @@ struct pc_kargs {
 	double *out_weights, *out_exit_coords, *out_exit_dir, *out_exit_elecv, *out_dtravel;
 	long long *out_irefl;
 };
+
+/* Stores of the compact image store: written through to memory (system-coherent), so that a block can be handed to the copy
+ * engine while the kernel runs without a write-back of the whole L2 (an agent-scope release on gfx950) per batch of photons */
+__device__ __forceinline__ void pc_store_wt(double *p, double v)
+{
+	__hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void pc_store_wt(long long *p, long long v)
+{
+	__hip_atomic_store((unsigned long long *)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+/* positions [base, base + k) have been written by this wave (k <= 64 < block size): count them into their blocks and
+ * publish a block that is complete.  Called by one lane after the wave's stores have been acknowledged. */
+__device__ __forceinline__ void pc_blocks_written(const pc_kargs &a, unsigned long long base, int k)
+{
+	if (!a.blk_done || k <= 0) return;
+	const unsigned long long B = 1ull << a.blk_shift;
+	unsigned long long b = base >> a.blk_shift;
+	unsigned long long left = (unsigned long long)k, at = base;
+	while (left) {
+		const unsigned long long end = (b + 1ull) << a.blk_shift;
+		const unsigned long long c = (end - at < left) ? end - at : left;
+		const unsigned long long size = ((unsigned long long)a.img_n - (b << a.blk_shift) < B) ? (unsigned long long)a.img_n - (b << a.blk_shift) : B;
+		const unsigned int old = __hip_atomic_fetch_add(&a.blk_done[b], (unsigned int)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if ((unsigned long long)old + c == size)
+			__hip_atomic_store(&a.blk_flag[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		left -= c; at += c; b++;
+	}
+}
+
+/* the 18 fields of one exit photon at position `pos` of the image store: src/polycap-source.c:779-798 (start images, from
+ * the sampled photon `s`) and :900-923 (exit images).  WT: stores written through (compact store). */
+template <bool WT>
+__device__ __forceinline__ void pc_store_field(double *p, double v)
+{
+	if (WT) pc_store_wt(p, v); else *p = v;
+}
+
+template <bool WT>
+__device__ __forceinline__ void pc_write_start_fields(const pc_kargs &a, long long pos, double srcx, double srcy, double x, double y,
+                                                      double dx, double dy, double evx, double evy)
+{
+	const long long fs = a.img_fs;
+	double *r = a.img + pos*a.img_ss;
+	pc_store_field<WT>(r + PC_F_SRCX*fs, srcx); pc_store_field<WT>(r + PC_F_SRCY*fs, srcy);
+	pc_store_field<WT>(r + PC_F_STARTX*fs, x); pc_store_field<WT>(r + PC_F_STARTY*fs, y);
+	pc_store_field<WT>(r + PC_F_SDIRX*fs, dx); pc_store_field<WT>(r + PC_F_SDIRY*fs, dy);
+	pc_store_field<WT>(r + PC_F_SEVX*fs, evx); pc_store_field<WT>(r + PC_F_SEVY*fs, evy);
+}
+
+/* start_electric_vector projected on the plane perpendicular to the direction, components rounded (:789-796) */
+__device__ __forceinline__ void pc_start_elecv_image(const pc_start &s, double cosalpha0, double &evx, double &evy)
+{
+	const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
+	double tx = s.ex*c_ae + s.dx*c_be, ty = s.ey*c_ae + s.dy*c_be, tz = s.ez*c_ae + s.dz*c_be;
+	pc_norm3(tx, ty, tz);
+	evx = round(tx); evy = round(ty);
+}
+
+template <bool WT>
+__device__ __forceinline__ void pc_write_exit_fields(const pc_kargs &a, const pc_params &Pm, long long pos, double Px, double Py, double Pz,
+                                                     double dx, double dy, double dz, double ex, double ey, double ez,
+                                                     double cosalpha0, long long irefl, double dtravel)
+{
+	const long long fs = a.img_fs;
+	double *r = a.img + pos*a.img_ss;
+	const double t = (Pm.z_end - Pz) / dz;
+	const double xx = Px + dx*t, xy = Py + dy*t, xz = Pz + dz*t;
+	pc_store_field<WT>(r + PC_F_EXITX*fs, xx); pc_store_field<WT>(r + PC_F_EXITY*fs, xy); pc_store_field<WT>(r + PC_F_EXITZ*fs, xz);
+	pc_store_field<WT>(r + PC_F_EDIRX*fs, dx); pc_store_field<WT>(r + PC_F_EDIRY*fs, dy);
+	const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
+	double tx = ex*c_ae + dx*c_be, ty = ey*c_ae + dy*c_be, tz = ez*c_ae + dz*c_be;
+	pc_norm3(tx, ty, tz);
+	pc_store_field<WT>(r + PC_F_EEVX*fs, round(tx)); pc_store_field<WT>(r + PC_F_EEVY*fs, round(ty));
+	if (WT) pc_store_wt((long long *)r + PC_F_NREFL*fs, irefl); else ((long long *)r)[PC_F_NREFL*fs] = irefl;
+	const double lx = xx - Px, ly = xy - Py, lz = Pm.z_end - Pz;
+	pc_store_field<WT>(r + PC_F_DTRAVEL*fs, dtravel + sqrt(lx*lx + ly*ly + lz*lz));
+}
 
 /* lane states on top of pc_device.h's: what the NEW phase has to do for the lane */
 enum { LS_IDLE = 0, LS_NEED_SLOT = 1, LS_START = 5, LS_MARCH = PC_ST_MARCH, LS_EVENT = PC_ST_EVENT, LS_DONE = PC_ST_DONE };
@@ -252,64 +347,99 @@ pc_trace_kernel(pc_kargs a)
 		const int total = __popcll(mF)*ne;
 		int q = 0, e = lane;
 		while (e >= ne) { e -= ne; q++; }
-		/* the next item's weight is fetched while the current one is computed (the rows live in HBM) */
-		unsigned info_n = 0u; double w_n = 1.0;
-		if (lane < total) {
-			info_n = map[q];
-			if (info_n >> 16) w_n = a.wscratch[(wave_gtid0 + (info_n & 255u))*(long long)ne + e];
-		}
-		for (int base = 0; base < total; base += PC_WAVE) {
-			const int act = base + lane < total;
-			const unsigned info = info_n;
-			double w = w_n;
-			const int qc = q, ec_i = e;
+		/* PC_SWEEP_IL items per lane are in flight together: independent Fresnel chains for the fp64 pipe, and the next group's
+		 * weights are fetched while the current one is computed (the rows live in HBM) */
+		constexpr int IL = PC_SWEEP_IL;
+		unsigned info_n[IL]; double w_n[IL]; int q_n[IL], e_n[IL];
+#pragma unroll
+		for (int il = 0; il < IL; il++) {
+			q_n[il] = q; e_n[il] = e;
+			info_n[il] = 0u; w_n[il] = 1.0;
+			if (il*PC_WAVE + lane < total) {
+				info_n[il] = map[q];
+				if (info_n[il] >> 16) w_n[il] = a.wscratch[(wave_gtid0 + (info_n[il] & 255u))*(long long)ne + e];
+			}
 			e += PC_WAVE;
 			while (e >= ne) { e -= ne; q++; }
-			info_n = 0u; w_n = 1.0;
-			if (base + PC_WAVE + lane < total) {
-				info_n = map[q];
-				if (info_n >> 16) w_n = a.wscratch[(wave_gtid0 + (info_n & 255u))*(long long)ne + e];
-			}
-			unsigned cnt = 0u;
-			int n = 0;
-			if (act) {
-				const int p = (int)(info & 255u);
-				n = (int)((info >> 8) & 255u);
-				const double *gq = l_pend + (size_t)(wave_t0 + p)*(3*PC_KB);
-				const double n_re = ecs[ec_i], n_im = ecs[ne + ec_i], a_re = ecs[2*ne + ec_i], a_im = ecs[3*ne + ec_i];
-				const double rgh = ROUGH ? ecs[4*ne + ec_i] : 0.;
-				double rmax = 0., rmin = 0.;
+		}
+		for (int base = 0; base < total; base += PC_WAVE*IL) {
+			int act[IL], qc[IL], ec_i[IL], n[IL], p[IL];
+			unsigned cnt[IL];
+			double w[IL];
+			const double *gq[IL];
+			double n_re[IL], n_im[IL], a_re[IL], a_im[IL], rgh[IL];
+			bool odd[IL];
 #pragma unroll
-				for (int r = 0; r < PC_KB; r++) {
-					if (r < n) {
-						const double ct = gq[3*r], es2 = gq[3*r + 1], sd2 = gq[3*r + 2];
-						double rt;
-						const double f = pc_fresnel_fast<ROUGH>(n_re, n_im, a_re, a_im, rgh, ct, fma(-ct, ct, 1.0), es2, sd2 - es2, sd2, rt);
-						rmax = fmax(rmax, rt); rmin = fmin(rmin, rt);
-						w = w*f;
-						cnt += (w >= 1.e-4) ? 1u : 0u;
-					}
+			for (int il = 0; il < IL; il++) {
+				act[il] = base + il*PC_WAVE + lane < total;
+				const unsigned info = info_n[il];
+				w[il] = w_n[il]; qc[il] = q_n[il]; ec_i[il] = e_n[il];
+				p[il] = (int)(info & 255u);
+				n[il] = act[il] ? (int)((info >> 8) & 255u) : 0;
+				cnt[il] = 0u; odd[il] = false;
+				/* an idle lane computes on photon 0 / energy e of its position (valid addresses) and stores nothing */
+				gq[il] = l_pend + (size_t)(wave_t0 + p[il])*(3*PC_KB);
+				const int ee = act[il] ? ec_i[il] : 0;
+				n_re[il] = ecs[ee]; n_im[il] = ecs[ne + ee]; a_re[il] = ecs[2*ne + ee]; a_im[il] = ecs[3*ne + ee];
+				rgh[il] = ROUGH ? ecs[4*ne + ee] : 0.;
+			}
+#pragma unroll
+			for (int il = 0; il < IL; il++) {
+				q_n[il] = q; e_n[il] = e;
+				info_n[il] = 0u; w_n[il] = 1.0;
+				if (base + (IL + il)*PC_WAVE + lane < total) {
+					info_n[il] = map[q];
+					if (info_n[il] >> 16) w_n[il] = a.wscratch[(wave_gtid0 + (info_n[il] & 255u))*(long long)ne + e];
 				}
-				a.wscratch[(wave_gtid0 + p)*(long long)ne + ec_i] = w;
-				if (rmax > 1. || rmin < 0.) {
+				e += PC_WAVE;
+				while (e >= ne) { e -= ne; q++; }
+			}
+#pragma unroll
+			for (int r = 0; r < PC_KB; r++) {
+				bool any = false;
+#pragma unroll
+				for (int il = 0; il < IL; il++) any |= r < n[il];
+				if (__ballot(any) == 0ull) break;
+#pragma unroll
+				for (int il = 0; il < IL; il++) {
+					const bool ok = r < n[il];
+					const double ct = gq[il][3*r], es2 = gq[il][3*r + 1], sd2 = gq[il][3*r + 2];
+					double rt;
+					const double f = pc_fresnel_fast<ROUGH>(n_re[il], n_im[il], a_re[il], a_im[il], rgh[il], ct, fma(-ct, ct, 1.0), es2, sd2 - es2, sd2, rt);
+					odd[il] |= ok && ((unsigned long long)__double_as_longlong(rt) > 0x3FF0000000000000ull);   /* negative, above 1 or NaN: looked at below */
+					w[il] = w[il]*(ok ? f : 1.0);
+					cnt[il] += (ok && w[il] >= 1.e-4) ? 1u : 0u;
+				}
+			}
+			bool short_any = false;
+#pragma unroll
+			for (int il = 0; il < IL; il++) {
+				if (act[il]) a.wscratch[(wave_gtid0 + p[il])*(long long)ne + ec_i[il]] = w[il];
+				if (odd[il]) {
 					/* never with physical constants: find this energy's first rejected reflection (rtot does not depend on the weight) */
 					unsigned fb = 255u;
-					for (int r = n - 1; r >= 0; r--) {
-						const double ct = gq[3*r], es2 = gq[3*r + 1], sd2 = gq[3*r + 2];
+					for (int r = n[il] - 1; r >= 0; r--) {
+						const double ct = gq[il][3*r], es2 = gq[il][3*r + 1], sd2 = gq[il][3*r + 2];
 						double rt;
-						(void)pc_fresnel_fast<false>(n_re, n_im, a_re, a_im, 0., ct, fma(-ct, ct, 1.0), es2, sd2 - es2, sd2, rt);
+						(void)pc_fresnel_fast<false>(n_re[il], n_im[il], a_re[il], a_im[il], 0., ct, fma(-ct, ct, 1.0), es2, sd2 - es2, sd2, rt);
 						if (rt < 0. || rt > 1.) fb = (unsigned)r;
 					}
-					atomicMin(&vbad[qc], fb);
+					atomicMin(&vbad[qc[il]], fb);
 				}
+				short_any |= act[il] && cnt[il] < (unsigned)n[il];
 			}
 			/* verdict: nearly always every energy of the pass kept its weight above 1e-4 through the whole batch -- then one
 			 * lane per photon says so; else every lane reports its count */
-			if (__ballot(act && cnt < (unsigned)n) == 0ull) {
-				const int q_left = __shfl_up(qc, 1, PC_WAVE);
-				if (act && (lane == 0 || q_left != qc)) atomicMax(&vcnt[qc], cnt);
-			} else if (act) {
-				atomicMax(&vcnt[qc], cnt);
+			if (__ballot(short_any) == 0ull) {
+#pragma unroll
+				for (int il = 0; il < IL; il++) {
+					const int q_left = __shfl_up(qc[il], 1, PC_WAVE);
+					if (act[il] && (lane == 0 || q_left != qc[il])) atomicMax(&vcnt[qc[il]], cnt[il]);
+				}
+			} else {
+#pragma unroll
+				for (int il = 0; il < IL; il++)
+					if (act[il]) atomicMax(&vcnt[qc[il]], cnt[il]);
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -513,7 +643,8 @@ pc_trace_kernel(pc_kargs a)
 			int f_exit = 0, f_not_entered = 0, f_not_trans = 0, f_failed = 0, f_launch = 0;   /* this lane's contributions */
 			unsigned int f_irefl = 0;
 			unsigned long long f_w = 0;
-			const long long done_slot = slot;
+			long long done_slot = slot;   /* where the finished photon's images go: its slot, or (compact store) the next free position */
+			int ok = 0;                   /* the photon left through the exit window: src/polycap-source.c:758-777 */
 			if (state == LS_DONE) {
 				const int rc = ph.rc;
 				if (EXPLICIT) {
@@ -532,61 +663,71 @@ pc_trace_kernel(pc_kargs a)
 					a.out_dtravel[j] = ph.dtravel;
 					state = LS_NEED_SLOT;
 				} else {
-					/* src/polycap-source.c:758-777 */
-					int ok = 0;
 					if (rc == 0) f_not_trans = 1;
 					else if (rc == 2) f_not_entered = 1;
 					else if (rc == 1) ok = pc_in_exit_window(Pm, ph);
-					if (ok) {
-						f_exit = 1;
-						f_irefl = (unsigned int)ph.irefl;
-						if (NE == 1) {
-							double w = ph.w[0];
-							f_w = (unsigned long long)(w * PC_FIX_SCALE);
-							if (a.keep_images) a.img_w[slot*ws] = w;
-						} else if (NE > 1) {
-							/* a few energies: exact sums in LDS (2 x u64 per energy), flushed once per workgroup */
+				}
+			}
+			/* compact store: the exit photons of this phase take the next positions of the planes, one coalesced run per plane */
+			const bool compact = !EXPLICIT && a.keep_images && a.img_cursor != nullptr;
+			unsigned long long c_base = 0ull;
+			int c_k = 0;
+			if (compact) {
+				const unsigned long long mOK = __ballot(ok);
+				if (mOK) {
+					c_k = __popcll(mOK);
+					if (lane == 0) c_base = atomicAdd(a.img_cursor, (unsigned long long)c_k);
+					c_base = __shfl(c_base, 0, PC_WAVE);
+					if (ok) done_slot = (long long)(c_base + (unsigned long long)__popcll(mOK & ((1ull << lane) - 1ull)));
+				}
+			}
+			if (!EXPLICIT && state == LS_DONE) {
+				if (ok) {
+					f_exit = 1;
+					f_irefl = (unsigned int)ph.irefl;
+					if (NE == 1) {
+						double w = ph.w[0];
+						f_w = (unsigned long long)(w * PC_FIX_SCALE);
+						if (a.keep_images) { if (compact) pc_store_wt(a.img_w + done_slot*ws, w); else a.img_w[done_slot*ws] = w; }
+					} else if (NE > 1) {
+						/* a few energies: exact sums in LDS (2 x u64 per energy), flushed once per workgroup */
 #pragma unroll
-							for (int e = 0; e < (NE > 0 ? NE : 1); e++) {
-								if (e < ner) {
-									double w = ph.w[NE > 0 ? e : 0];
-									unsigned long long f = (unsigned long long)(w * PC_FIX_SCALE);
-									unsigned long long old = atomicAdd(&l_acc[2*e], f);
-									if (old + f < old) atomicAdd(&l_acc[2*e + 1], 1ull);
-									if (a.keep_images) a.img_w[slot*ws + e] = w;
-								}
+						for (int e = 0; e < (NE > 0 ? NE : 1); e++) {
+							if (e < ner) {
+								double w = ph.w[NE > 0 ? e : 0];
+								unsigned long long f = (unsigned long long)(w * PC_FIX_SCALE);
+								unsigned long long old = atomicAdd(&l_acc[2*e], f);
+								if (old + f < old) atomicAdd(&l_acc[2*e + 1], 1ull);
+								if (a.keep_images) { if (compact) pc_store_wt(a.img_w + done_slot*ws + e, w); else a.img_w[done_slot*ws + e] = w; }
 							}
-						} else {
-							coop = 1;    /* sums and image weights are handled by the cooperative sweep below */
 						}
-						if (a.keep_images) {
-							/* src/polycap-source.c:900-923 */
-							double *r = a.img + slot*ss;
-							double t = (Pm.z_end - ph.Pz) / ph.dz;
-							double ex = ph.Px + ph.dx*t, ey = ph.Py + ph.dy*t, ez = ph.Pz + ph.dz*t;
-							r[PC_F_EXITX*fs] = ex; r[PC_F_EXITY*fs] = ey; r[PC_F_EXITZ*fs] = ez;
-							r[PC_F_EDIRX*fs] = ph.dx; r[PC_F_EDIRY*fs] = ph.dy;
-							const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
-							double tx = ph.ex*c_ae + ph.dx*c_be, ty = ph.ey*c_ae + ph.dy*c_be, tz = ph.ez*c_ae + ph.dz*c_be;
-							pc_norm3(tx, ty, tz);
-							r[PC_F_EEVX*fs] = round(tx); r[PC_F_EEVY*fs] = round(ty);
-							((long long *)r)[PC_F_NREFL*fs] = ph.irefl;
-							double lx = ex - ph.Px, ly = ey - ph.Py, lz = Pm.z_end - ph.Pz;
-							r[PC_F_DTRAVEL*fs] = ph.dtravel + sqrt(lx*lx + ly*ly + lz*lz);
+					} else {
+						coop = 1;    /* sums and image weights are handled by the cooperative sweep below */
+					}
+					if (a.keep_images) {
+						/* src/polycap-source.c:900-923 */
+						if (compact) {
+							/* the start images waited in the lane's own line (written at the launch, below) */
+							const double *ls = a.lane_start + gtid*8;
+							pc_write_start_fields<true>(a, done_slot, ls[0], ls[1], ls[2], ls[3], ls[4], ls[5], ls[6], ls[7]);
+							pc_write_exit_fields<true>(a, Pm, done_slot, ph.Px, ph.Py, ph.Pz, ph.dx, ph.dy, ph.dz, ph.ex, ph.ey, ph.ez, cosalpha0, (long long)ph.irefl, ph.dtravel);
+							if (a.img_ids) pc_store_wt(a.img_ids + done_slot, slot);
+						} else {
+							pc_write_exit_fields<false>(a, Pm, done_slot, ph.Px, ph.Py, ph.Pz, ph.dx, ph.dy, ph.dz, ph.ex, ph.ey, ph.ez, cosalpha0, (long long)ph.irefl, ph.dtravel);
+						}
+					}
+					state = LS_NEED_SLOT;
+				} else {
+					attempt++;
+					if (attempt >= a.max_attempts) {
+						f_failed = 1;
+						if (a.keep_images && !compact) {
+							if (NE > 0) for (int e = 0; e < ner; e++) a.img_w[slot*ws + e] = 0.;
+							else coop = 2;   /* zero weights */
 						}
 						state = LS_NEED_SLOT;
 					} else {
-						attempt++;
-						if (attempt >= a.max_attempts) {
-							f_failed = 1;
-							if (a.keep_images) {
-								if (NE > 0) for (int e = 0; e < ner; e++) a.img_w[slot*ws + e] = 0.;
-								else coop = 2;   /* zero weights */
-							}
-							state = LS_NEED_SLOT;
-						} else {
-							state = LS_START;
-						}
+						state = LS_START;
 					}
 				}
 			}
@@ -673,14 +814,15 @@ pc_trace_kernel(pc_kargs a)
 						 * the slot belongs to this lane, so a later (transmitted) attempt simply overwrites them */
 						cosalpha0 = s.ex*s.dx + s.ey*s.dy + s.ez*s.dz;
 						if (a.keep_images) {
-							const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
-							double *r = a.img + slot*ss;
-							r[PC_F_SRCX*fs] = s.srcx; r[PC_F_SRCY*fs] = s.srcy;
-							r[PC_F_STARTX*fs] = s.x; r[PC_F_STARTY*fs] = s.y;
-							r[PC_F_SDIRX*fs] = s.dx; r[PC_F_SDIRY*fs] = s.dy;
-							double tx = s.ex*c_ae + s.dx*c_be, ty = s.ey*c_ae + s.dy*c_be, tz = s.ez*c_ae + s.dz*c_be;
-							pc_norm3(tx, ty, tz);
-							r[PC_F_SEVX*fs] = round(tx); r[PC_F_SEVY*fs] = round(ty);
+							double evx, evy;
+							pc_start_elecv_image(s, cosalpha0, evx, evy);
+							if (a.img_cursor) {
+								/* compact store: the position is known when the photon leaves; until then its line */
+								double *ls = a.lane_start + gtid*8;
+								ls[0] = s.srcx; ls[1] = s.srcy; ls[2] = s.x; ls[3] = s.y; ls[4] = s.dx; ls[5] = s.dy; ls[6] = evx; ls[7] = evy;
+							} else {
+								pc_write_start_fields<false>(a, slot, s.srcx, s.srcy, s.x, s.y, s.dx, s.dy, evx, evy);
+							}
 						}
 					}
 				}
@@ -942,6 +1084,23 @@ struct pc_hip_ctx {
 	long long soa_slots = 0;
 	int plane_images = 0;                  /* option "plane_images": runs that keep images write the planes themselves (no records) */
 	int run_planes = 0;                    /* the last run did so */
+	/* option "compact_images" (with plane_images): exit photons are stored in the order of completion, one coalesced run per
+	 * plane and batch, and the planes are published block by block while the kernel runs (pc_kargs::img_cursor) */
+	int compact_images = 0;
+	int run_compact = 0;                   /* the last run did so */
+	int slot_ids = 0;                      /* option "slot_ids": compact runs also store which slot sits at which position */
+	int blk_shift = 18;                    /* option "block_shift": published blocks of 2^blk_shift positions (262144: 2 MB per plane) */
+	int run_blk_shift = 18;
+	long long run_blocks = 0;
+	unsigned long long *d_cursor = nullptr;
+	unsigned int *d_blk_done = nullptr;
+	size_t blk_capacity = 0;
+	unsigned int *h_blk_flag = nullptr;    /* host memory mapped into the device: 1 when a block is complete */
+	unsigned int *d_blk_flag = nullptr;    /* its device address */
+	long long *d_ids = nullptr;
+	long long ids_slots = 0;
+	double *d_lane_start = nullptr;
+	size_t lane_start_elems = 0;
 	double *d_wscratch = nullptr;
 	size_t wscratch_elems = 0;
 	/* explicit-photon calls (polycap_photon_launch, polycap_source_get_photon): one device buffer and one pinned host
@@ -1155,6 +1314,11 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->d_work) (void)hipFree(ctx->d_work);
 	if (ctx->ev_sync) (void)hipEventDestroy(ctx->ev_sync);
 	if (ctx->d_wscratch) (void)hipFree(ctx->d_wscratch);
+	if (ctx->d_cursor) (void)hipFree(ctx->d_cursor);
+	if (ctx->d_blk_done) (void)hipFree(ctx->d_blk_done);
+	if (ctx->h_blk_flag) (void)hipHostFree(ctx->h_blk_flag);
+	if (ctx->d_ids) (void)hipFree(ctx->d_ids);
+	if (ctx->d_lane_start) (void)hipFree(ctx->d_lane_start);
 	if (ctx->d_batch) (void)hipFree(ctx->d_batch);
 	if (ctx->h_batch) { if (ctx->h_batch_pinned) (void)hipHostFree(ctx->h_batch); else free(ctx->h_batch); }
 	if (ctx->d_leak_frames) (void)hipFree(ctx->d_leak_frames);
@@ -1239,6 +1403,9 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "lds_ec") ctx->lds_ec = value ? 1 : 0;
 	else if (n == "batch_reflections") ctx->batch_reflections = value ? 1 : 0;
 	else if (n == "plane_images") ctx->plane_images = value ? 1 : 0;
+	else if (n == "compact_images") ctx->compact_images = value ? 1 : 0;
+	else if (n == "slot_ids") ctx->slot_ids = value ? 1 : 0;
+	else if (n == "block_shift") { if (value < 7 || value > 30) return pc_fail(PC_HIP_ERR_INVALID, "block_shift must be in [7,30]"); ctx->blk_shift = (int)value; }
 	else if (n == "run_parts") { if (value < 1 || value > PC_MAX_PARTS) return pc_fail(PC_HIP_ERR_INVALID, "run_parts must be in [1,16]"); ctx->run_parts = (int)value; }
 	else if (n == "fetch_threads") { if (value < 0 || value > 256) return pc_fail(PC_HIP_ERR_INVALID, "fetch_threads must be in [0,256]"); ctx->fetch_threads = (int)value; }
 	else if (n == "pool") ctx->pool = value ? 1 : 0;
@@ -1454,6 +1621,50 @@ static long long pc_part_begin(long long n_slots, int parts, int k)
 /* image planes: 17 double-sized planes of n_slots entries followed by the weights plane */
 static const int PC_N_PLANES = 17;
 
+/* buffers of a compact run of n_slots (pc_kargs::img_cursor): position counter, per-block counters, the host-visible block
+ * flags, the lanes' start-image lines and, on request, the plane of slot indices; counters and flags are cleared */
+static int pc_compact_prepare(pc_hip_ctx *ctx, long long n_slots)
+{
+	const int shift = ctx->blk_shift;
+	const size_t blocks = (size_t)((n_slots + (1ll << shift) - 1) >> shift);
+	if (!ctx->d_cursor) PC_HIP_CHECK(hipMalloc(&ctx->d_cursor, sizeof(unsigned long long)));
+	if (ctx->blk_capacity < blocks) {
+		if (ctx->d_blk_done) (void)hipFree(ctx->d_blk_done);
+		if (ctx->h_blk_flag) (void)hipHostFree(ctx->h_blk_flag);
+		ctx->d_blk_done = nullptr; ctx->h_blk_flag = nullptr; ctx->d_blk_flag = nullptr; ctx->blk_capacity = 0;
+		const size_t cap = blocks + blocks/2 + 16;
+		PC_HIP_CHECK(hipMalloc(&ctx->d_blk_done, cap*sizeof(unsigned int)));
+		if (hipHostMalloc(&ctx->h_blk_flag, cap*sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+			(void)hipGetLastError();
+			PC_HIP_CHECK(hipHostMalloc(&ctx->h_blk_flag, cap*sizeof(unsigned int), hipHostMallocMapped));
+		}
+		PC_HIP_CHECK(hipHostGetDevicePointer((void **)&ctx->d_blk_flag, ctx->h_blk_flag, 0));
+		ctx->blk_capacity = cap;
+	}
+	if (ctx->slot_ids && ctx->ids_slots < n_slots) {
+		if (ctx->d_ids) (void)hipFree(ctx->d_ids);
+		ctx->d_ids = nullptr; ctx->ids_slots = 0;
+		if (hipMalloc(&ctx->d_ids, (size_t)n_slots*sizeof(long long)) != hipSuccess) { (void)hipGetLastError(); return pc_fail(PC_HIP_ERR_MEMORY, "pc_hip_transmission_run: could not allocate the slot-index plane"); }
+		ctx->ids_slots = n_slots;
+	}
+	{
+		/* one 64-byte line per lane of the largest launch the context makes */
+		const size_t lanes = (size_t)ctx->n_cu * (size_t)std::max(ctx->blocks_per_cu*ctx->block_size, 1024);
+		if (ctx->lane_start_elems < 8*lanes) {
+			if (ctx->d_lane_start) (void)hipFree(ctx->d_lane_start);
+			ctx->d_lane_start = nullptr; ctx->lane_start_elems = 0;
+			PC_HIP_CHECK(hipMalloc(&ctx->d_lane_start, 8*lanes*sizeof(double)));
+			ctx->lane_start_elems = 8*lanes;
+		}
+	}
+	ctx->run_blk_shift = shift;
+	ctx->run_blocks = (long long)blocks;
+	memset(ctx->h_blk_flag, 0, blocks*sizeof(unsigned int));      /* the previous run has been waited for: nobody looks at them now */
+	PC_HIP_CHECK(hipMemsetAsync(ctx->d_cursor, 0, sizeof(unsigned long long), ctx->stream));
+	PC_HIP_CHECK(hipMemsetAsync(ctx->d_blk_done, 0, blocks*sizeof(unsigned int), ctx->stream));
+	return PC_HIP_OK;
+}
+
 int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64_t n_slots, uint32_t max_attempts, int keep_images)
 {
 	if (!ctx) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_run: ctx must not be NULL");
@@ -1479,6 +1690,19 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 	 * 5 % of the HBM bandwidth at most -- and the fetch is a plain copy of planes into the caller's pinned memory */
 	const bool planes = keep_images && ctx->plane_images && pc_soa_ensure(ctx, n_slots) == PC_HIP_OK;
 	ctx->run_planes = planes ? 1 : 0;
+	const bool compact = planes && ctx->compact_images;
+	ctx->run_compact = compact ? 1 : 0;
+	if (compact) {
+		int st = pc_compact_prepare(ctx, n_slots);
+		if (st) return st;
+		a.img_cursor = ctx->d_cursor;
+		a.img_ids = ctx->slot_ids ? ctx->d_ids : nullptr;
+		a.blk_done = ctx->d_blk_done;
+		a.blk_flag = ctx->d_blk_flag;
+		a.blk_shift = ctx->run_blk_shift;
+		a.img_n = n_slots;
+		a.lane_start = ctx->d_lane_start;
+	}
 	if (keep_images && !planes) {
 		if (ctx->img_slots < n_slots) {
 			if (ctx->d_img) PC_HIP_CHECK(hipFree(ctx->d_img));
@@ -1493,7 +1717,7 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 	a.seed = seed; a.max_attempts = max_attempts; a.keep_images = keep_images ? 1 : 0;
 	/* parts: consecutive slot ranges traced by consecutive launches into the same totals and image records (a photon
 	 * depends on its global slot number only, so the result does not depend on the cut) */
-	int parts = (keep_images && ctx->run_parts > 1) ? ctx->run_parts : 1;
+	int parts = (keep_images && ctx->run_parts > 1 && !compact) ? ctx->run_parts : 1;      /* a compact run publishes its blocks itself */
 	if (parts > PC_MAX_PARTS) parts = PC_MAX_PARTS;
 	if ((long long)parts > n_slots / 65536) parts = (int)(n_slots / 65536);
 	if (parts < 1) parts = 1;
@@ -1725,7 +1949,41 @@ static int pc_fetch_planes_direct(pc_hip_ctx *ctx, int64_t first, int64_t count,
 	}
 	const double t_pinned = now_ms();
 	int status = PC_HIP_OK;
-	const int parts = ctx->n_parts > 1 ? ctx->n_parts : 1;
+	const int parts = ctx->run_compact ? 0 : (ctx->n_parts > 1 ? ctx->n_parts : 1);
+	if (ctx->run_compact) {
+		/* the kernel publishes its planes block by block (pc_blocks_written): every block is copied as soon as its flag is up,
+		 * while the kernel goes on.  The kernel's end also ends the wait (every block is complete then). */
+		const long long B = 1ll << ctx->run_blk_shift;
+		bool kernel_done = false;
+		for (long long b = first >> ctx->run_blk_shift; b < ctx->run_blocks && b*B < first + count && status == PC_HIP_OK; b++) {
+			volatile unsigned int *flag = ctx->h_blk_flag + b;
+			unsigned long spins = 0;
+			while (!kernel_done && *flag == 0u) {
+				if ((++spins & 63ul) == 0ul) {
+					const hipError_t q = hipEventQuery(ctx->ev1);
+					if (q == hipSuccess) kernel_done = true;
+					else if (q != hipErrorNotReady) { status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_transmission_images: ") + hipGetErrorString(q)); break; }
+					(void)hipGetLastError();
+				}
+				std::this_thread::yield();
+			}
+			if (status != PC_HIP_OK) break;
+			std::atomic_thread_fence(std::memory_order_acquire);
+			const long long lo = std::max<long long>(b*B, first), hi = std::min<long long>(std::min<long long>((b + 1)*B, n_total), first + count);
+			hipError_t e = hipSuccess;
+			for (int f = 0; f <= PC_N_FIELDS && e == hipSuccess; f++) {
+				if (f < PC_N_FIELDS) {
+					if (!planes[f]) continue;
+					e = hipMemcpyAsync((double *)planes[f] + (lo - first), ctx->d_soa + (size_t)f*n_total + lo, (size_t)(hi - lo)*sizeof(double),
+					                   hipMemcpyDeviceToHost, ctx->fetch_stream);
+				} else if (weights) {
+					e = hipMemcpyAsync(weights + (size_t)(lo - first)*ne, ctx->d_soa + (size_t)PC_N_FIELDS*n_total + (size_t)lo*ne,
+					                   (size_t)(hi - lo)*ne*sizeof(double), hipMemcpyDeviceToHost, ctx->fetch_stream);
+				}
+			}
+			if (e != hipSuccess) status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_transmission_images: ") + hipGetErrorString(e));
+		}
+	}
 	for (int k = 0; k < parts && status == PC_HIP_OK; k++) {
 		const long long plo = (parts > 1 && k > 0) ? ctx->part_end[k - 1] : 0, phi = (parts > 1) ? ctx->part_end[k] : n_total;
 		const long long lo = std::max<long long>(plo, first), hi = std::min<long long>(phi, first + count);
@@ -1770,7 +2028,7 @@ static int pc_fetch_images(pc_hip_ctx *ctx, int64_t first, int64_t count, const 
 	if (!ctx->img_valid) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: the last run kept no images");
 	if (first < 0 || count < 0 || first + count > ctx->run_slots) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: slot range out of bounds");
 	/* a leak run is complete (and possibly repeated) only after wait(); a plain run is fetched part by part below */
-	if (ctx->leak_pending || ctx->n_parts <= 1) {
+	if (ctx->leak_pending || (ctx->n_parts <= 1 && !(ctx->run_compact && dst && !raw))) {
 		int st = pc_hip_transmission_wait(ctx, nullptr);
 		if (st) return st;
 	}
@@ -1871,6 +2129,22 @@ int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, int64_t count, co
 {
 	if (!ctx || !dst) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_images: NULL argument");
 	return pc_fetch_images(ctx, first, count, dst, nullptr);
+}
+
+int pc_hip_transmission_slot_ids(pc_hip_ctx *ctx, int64_t first, int64_t count, int64_t *slots)
+{
+	if (!ctx || (count > 0 && !slots)) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_slot_ids: NULL argument");
+	if (first < 0 || count < 0 || first + count > ctx->run_slots) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_slot_ids: range out of bounds");
+	int st = pc_hip_transmission_wait(ctx, nullptr);
+	if (st) return st;
+	if (!ctx->img_valid || !ctx->run_compact || !ctx->d_ids || !ctx->slot_ids) {
+		/* a run that stores every photon at its slot: the identity */
+		for (int64_t k = 0; k < count; k++) slots[k] = first + k;
+		return PC_HIP_OK;
+	}
+	PC_HIP_CHECK(hipSetDevice(ctx->device));
+	if (count) PC_HIP_CHECK(hipMemcpy(slots, ctx->d_ids + first, (size_t)count*sizeof(long long), hipMemcpyDeviceToHost));
+	return PC_HIP_OK;
 }
 
 int pc_hip_transmission_records(pc_hip_ctx *ctx, int64_t first, int64_t count, double *records)

@@ -159,7 +159,7 @@ pc_trace_producer_kernel(pc_kargs a)
 						if (ok) {
 							f_exit = 1;
 							f_w = (unsigned long long)(gw * PC_FIX_SCALE);
-							if (a.keep_images) {
+							if (a.keep_images && !a.img_cursor) {
 								double *r = a.img + g_slot*ss;
 								const double cosalpha0 = __longlong_as_double((long long)__hip_atomic_load((unsigned long long *)(r + PC_F_EEVX*fs),
 								                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -178,7 +178,7 @@ pc_trace_producer_kernel(pc_kargs a)
 							}
 						} else if (g_att + 1 >= a.max_attempts) {
 							f_fail = 1;
-							if (a.keep_images) { a.img_w[g_slot*ws] = 0.; a.img[g_slot*ss + PC_F_EEVX*fs] = 0.; }
+							if (a.keep_images && !a.img_cursor) { a.img_w[g_slot*ws] = 0.; a.img[g_slot*ss + PC_F_EEVX*fs] = 0.; }
 						} else {
 							f_slot = g_slot; f_att = g_att + 1; have = 1;
 						}
@@ -186,6 +186,31 @@ pc_trace_producer_kernel(pc_kargs a)
 					u_not_trans += (unsigned long long)__popcll(__ballot(f_nt));
 					u_failed += (unsigned long long)__popcll(__ballot(f_fail));
 					const unsigned long long mX = __ballot(f_exit);
+					if (a.keep_images && a.img_cursor && mX) {
+						/* compact store: the exit photons of this batch take the next positions of the planes -- one coalesced run per
+						 * plane -- and everything about them is written here, once: the start images are sampled again from
+						 * (seed, slot, attempt), which costs this wave ~400 instructions per batch and no memory traffic */
+						const int kx = __popcll(mX);
+						unsigned long long base = 0ull;
+						if (lane == 0) base = atomicAdd(a.img_cursor, (unsigned long long)kx);
+						base = __shfl(base, 0, PC_WAVE);
+						if (f_exit) {
+							const long long pos = (long long)(base + (unsigned long long)__popcll(mX & below));
+							pc_start s;
+							pc_sample_photon<MODE == PC_MODE_SRC_GENERIC>(Pm, a.seed, (unsigned long long)(a.slot0 + g_slot), g_att, s);
+							const double cosalpha0 = s.ex*s.dx + s.ey*s.dy + s.ez*s.dz;
+							double evx, evy;
+							pc_start_elecv_image(s, cosalpha0, evx, evy);
+							pc_write_start_fields<true>(a, pos, s.srcx, s.srcy, s.x, s.y, s.dx, s.dy, evx, evy);
+							pc_write_exit_fields<true>(a, Pm, pos, gPx, gPy, gPz, gdx, gdy, gdz, gex, gey, gez, cosalpha0, (long long)g_irefl, gdt);
+							pc_store_wt(a.img_w + pos*ws, gw);
+							if (a.img_ids) pc_store_wt(a.img_ids + pos, g_slot);
+						}
+						if (a.blk_done) {
+							asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* the stores above have reached memory */
+							if (lane == 0) pc_blocks_written(a, base, kx);
+						}
+					}
 					const int nfin = __popcll(mX) + __popcll(__ballot(f_fail));
 					if (nfin > 0 && lane == 0) atomicSub(&ctl.outstanding, (unsigned int)nfin);
 					if (mX) {
@@ -268,7 +293,7 @@ pc_trace_producer_kernel(pc_kargs a)
 				const int st = pc_launch_init(T, Pm, np, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez);
 				if (st == PC_ST_MARCH) {
 					entered = 1;
-					if (a.keep_images) {
+					if (a.keep_images && !a.img_cursor) {
 						/* src/polycap-source.c:779-798 */
 						const double cosalpha0 = s.ex*s.dx + s.ey*s.dy + s.ez*s.dz;
 						const double c_ae = 1.0 / sqrt(1.0 - cosalpha0*cosalpha0), c_be = -1.*c_ae*cosalpha0;
@@ -287,7 +312,7 @@ pc_trace_producer_kernel(pc_kargs a)
 					if (f_att >= a.max_attempts) {
 						f_fail = 1;
 						have = 0;
-						if (a.keep_images) { a.img_w[f_slot*ws] = 0.; a.img[f_slot*ss + PC_F_EEVX*fs] = 0.; }
+						if (a.keep_images && !a.img_cursor) { a.img_w[f_slot*ws] = 0.; a.img[f_slot*ss + PC_F_EEVX*fs] = 0.; }
 					}
 				}
 			}

@@ -414,7 +414,7 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 		n_devices = 1;      /* leak runs keep their event lists on one device: the first of the list */
 	double t_stage[8];
 	t_stage[0] = pc_now_ms();
-	polycap_transmission_efficiencies *eff = pc_transeff_alloc(source, keep_images ? (size_t)n_photons : 0, "polycap_source_get_transmission_efficiencies", error);
+	polycap_transmission_efficiencies *eff = pc_transeff_alloc(source, keep_images ? (size_t)n_photons : 0, 0, "polycap_source_get_transmission_efficiencies", error);
 	double *sum_weights = malloc(sizeof(double)*ne);
 	if (eff == NULL || sum_weights == NULL) {
 		if (eff != NULL)
@@ -448,14 +448,23 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 	int status;
 	/* big plain runs are traced in four parts so that the images of a finished part cross PCIe while the next part runs */
 	const int parts = (!leak_calc && keep_images && n_photons >= 2000000) ? (int)pc_env_u64("POLYCAP_RUN_PARTS", 4, NULL) : 1;
+	/* Plain runs store their exit photons in the order of completion (option "compact_images": coalesced plane stores, blocks
+	 * copied to the host while the kernel runs); the reference's own order is the order in which randomly seeded threads fill
+	 * the arrays.  POLYCAP_COMPACT=0 keeps every photon at the position of its slot (reproducible order for a given POLYCAP_SEED). */
+	const char *compact_env = getenv("POLYCAP_COMPACT");
+	const int compact = !(compact_env != NULL && strcmp(compact_env, "0") == 0) && !leak_calc;
 	if (group != NULL) {
 		status = pc_hip_group_set_option(group, "run_parts", parts);
+		if (status == PC_HIP_OK)
+			status = pc_hip_group_set_option(group, "compact_images", compact);
 		if (status == PC_HIP_OK)
 			status = pc_hip_group_set_option(group, "plane_images", 1);
 		if (status == PC_HIP_OK)
 			status = pc_hip_group_run(group, seed, n_photons, max_attempts, keep_images);
 	} else {
 		status = pc_hip_set_option(ctx, "run_parts", parts);
+		if (status == PC_HIP_OK)
+			status = pc_hip_set_option(ctx, "compact_images", compact);
 		if (status == PC_HIP_OK)
 			status = pc_hip_set_option(ctx, "plane_images", leak_calc ? 0 : 1);   /* the result object wants planes: let the kernel write them */
 		if (status == PC_HIP_OK)

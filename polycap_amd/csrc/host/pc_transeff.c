@@ -25,17 +25,52 @@
 #define PC_HUGE_PAGE ((size_t)2 << 20)
 struct pc_plane_hdr { uint64_t magic; void *base; size_t len; uint64_t mapped; uint64_t pad[4]; };
 
-static void *pc_plane_calloc(size_t n, size_t size)
+/* Freed planes of 4 MB and more are kept in a small pool (at most PC_POOL_PLANES planes, PC_POOL_BYTES bytes in all: one result
+ * of 1e7 photons) and handed out again to the next result of the same size: their pages are faulted in and -- once a fetch
+ * has pinned them for the copy engine (pc_hip_host_register) -- pinned, which saves the next call ~3 ms of hipHostRegister and
+ * the page faults of 1.4 GB before its first copy can start.  A pooled plane keeps its old contents: `zeroed` asks for the
+ * calloc semantics (memset), callers that overwrite every entry do without.  POLYCAP_HOST_POOL=0 disables the pool. */
+#define PC_POOL_PLANES 24
+#define PC_POOL_BYTES ((size_t)3 << 30)
+struct pc_pool_entry { void *user; size_t bytes; };
+static struct pc_pool_entry g_pool[PC_POOL_PLANES];
+static int g_pool_n = 0;
+static size_t g_pool_bytes = 0;
+static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static int pc_pool_enabled(void)
+{
+	const char *e = getenv("POLYCAP_HOST_POOL");
+	return !(e != NULL && strcmp(e, "0") == 0);
+}
+
+static void *pc_plane_calloc(size_t n, size_t size, int zeroed)
 {
 	if (size != 0 && n > (SIZE_MAX - 2*PC_HUGE_PAGE)/size) { errno = ENOMEM; return NULL; }
 	const size_t bytes = n*size;
 	struct pc_plane_hdr h = { PC_PLANE_MAGIC, NULL, 0, 0, {0, 0, 0, 0} };
 	char *user;
 	if (bytes >= 2*PC_HUGE_PAGE) {
+		void *pooled = NULL;
+		pthread_mutex_lock(&g_pool_mu);
+		for (int k = 0; k < g_pool_n; k++) {
+			if (g_pool[k].bytes == bytes) {
+				pooled = g_pool[k].user;
+				g_pool_bytes -= bytes;
+				g_pool[k] = g_pool[--g_pool_n];
+				break;
+			}
+		}
+		pthread_mutex_unlock(&g_pool_mu);
+		if (pooled != NULL) {
+			if (zeroed) memset(pooled, 0, bytes);
+			return pooled;
+		}
 		h.len = bytes + sizeof(h) + PC_HUGE_PAGE;
 		h.base = mmap(NULL, h.len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
 		if (h.base == MAP_FAILED) return NULL;
 		h.mapped = 1;
+		h.pad[1] = bytes;
 		const uintptr_t first = (uintptr_t)h.base + sizeof(h);
 		user = (char *)((first + PC_HUGE_PAGE - 1) & ~(uintptr_t)(PC_HUGE_PAGE - 1));
 		(void)madvise(user, bytes, MADV_HUGEPAGE);     /* advisory: without THP the mapping is simply small pages */
@@ -48,14 +83,60 @@ static void *pc_plane_calloc(size_t n, size_t size)
 	return user;
 }
 
+/* header word 0 of a mapped plane: pinned by pc_hip_host_register (stays so while the plane lives or waits in the pool) */
+static void pc_plane_set_pinned(void *plane, int pinned)
+{
+	if (plane == NULL) return;
+	struct pc_plane_hdr *h = (struct pc_plane_hdr *)((char *)plane - sizeof(struct pc_plane_hdr));
+	if (h->magic == PC_PLANE_MAGIC && h->mapped) h->pad[0] = pinned ? 1 : 0;
+}
+
+static int pc_plane_pooled_ready(const void *plane)
+{
+	if (plane == NULL) return 0;
+	const struct pc_plane_hdr *h = (const struct pc_plane_hdr *)((const char *)plane - sizeof(struct pc_plane_hdr));
+	return h->magic == PC_PLANE_MAGIC && h->mapped && h->pad[0] == 1;
+}
+
 static void pc_plane_free(void *plane)
 {
 	if (plane == NULL) return;
 	struct pc_plane_hdr h;
 	memcpy(&h, (char *)plane - sizeof(h), sizeof(h));
 	if (h.magic != PC_PLANE_MAGIC) return;      /* not one of ours: leave it alone rather than guess */
-	if (h.mapped) munmap(h.base, h.len);
-	else free(h.base);
+	if (h.mapped) {
+		const size_t bytes = (size_t)h.pad[1];
+		if (pc_pool_enabled()) {
+			int kept = 0;
+			pthread_mutex_lock(&g_pool_mu);
+			if (g_pool_n < PC_POOL_PLANES && g_pool_bytes + bytes <= PC_POOL_BYTES) {
+				g_pool[g_pool_n].user = plane; g_pool[g_pool_n].bytes = bytes; g_pool_n++;
+				g_pool_bytes += bytes;
+				kept = 1;
+			}
+			pthread_mutex_unlock(&g_pool_mu);
+			if (kept) return;
+		}
+		if (h.pad[0]) pc_hip_host_unregister(plane);
+		munmap(h.base, h.len);
+	} else {
+		free(h.base);
+	}
+}
+
+/* empties the pool (tests; POLYCAP_HOST_POOL=0 stops refilling it) */
+void pc_host_pool_clear(void)
+{
+	pthread_mutex_lock(&g_pool_mu);
+	while (g_pool_n > 0) {
+		void *plane = g_pool[--g_pool_n].user;
+		struct pc_plane_hdr h;
+		memcpy(&h, (char *)plane - sizeof(h), sizeof(h));
+		if (h.pad[0]) pc_hip_host_unregister(plane);
+		munmap(h.base, h.len);
+	}
+	g_pool_bytes = 0;
+	pthread_mutex_unlock(&g_pool_mu);
 }
 
 static void pc_images_free(struct _polycap_images *images)
@@ -107,7 +188,7 @@ void polycap_transmission_efficiencies_free(polycap_transmission_efficiencies *e
 }
 
 /* result object with every plane allocated for np exit photons (reference: src/polycap-source.c:556-681) */
-polycap_transmission_efficiencies *pc_transeff_alloc(polycap_source *source, size_t np, const char *caller, polycap_error **error)
+polycap_transmission_efficiencies *pc_transeff_alloc(polycap_source *source, size_t np, int zeroed, const char *caller, polycap_error **error)
 {
 	const size_t ne = source->n_energies;
 	const size_t nalloc = np ? np : 1;
@@ -127,11 +208,11 @@ polycap_transmission_efficiencies *pc_transeff_alloc(polycap_source *source, siz
 			&im->pc_exit_dir[0], &im->pc_exit_dir[1], &im->pc_exit_elecv[0], &im->pc_exit_elecv[1], &im->pc_exit_dtravel };
 		alloc_ok = (eff->energies != NULL && eff->efficiencies != NULL);
 		for (size_t k = 0; k < sizeof(planes)/sizeof(planes[0]); k++) {
-			*planes[k] = pc_plane_calloc(nalloc, sizeof(double));
+			*planes[k] = pc_plane_calloc(nalloc, sizeof(double), zeroed);
 			alloc_ok = alloc_ok && (*planes[k] != NULL);
 		}
-		im->pc_exit_nrefl = pc_plane_calloc(nalloc, sizeof(int64_t));
-		im->exit_coord_weights = pc_plane_calloc(nalloc*ne, sizeof(double));
+		im->pc_exit_nrefl = pc_plane_calloc(nalloc, sizeof(int64_t), zeroed);
+		im->exit_coord_weights = pc_plane_calloc(nalloc*ne, sizeof(double), zeroed);
 		alloc_ok = alloc_ok && im->pc_exit_nrefl != NULL && im->exit_coord_weights != NULL;
 	}
 	if (!alloc_ok) {
@@ -198,8 +279,10 @@ void pc_transeff_prefault(polycap_transmission_efficiencies *eff, size_t np)
 		d.pc_exit_coords[0], d.pc_exit_coords[1], d.pc_exit_coords[2], d.pc_exit_dir[0], d.pc_exit_dir[1],
 		d.pc_exit_elecv[0], d.pc_exit_elecv[1], d.pc_exit_nrefl, d.pc_exit_dtravel };
 	for (size_t k = 0; k < sizeof(planes)/sizeof(planes[0]); k++)
-		if (planes[k] != NULL) { jobs[nj].base = planes[k]; jobs[nj].bytes = np*sizeof(double); nj++; }
-	if (d.exit_coord_weights != NULL) { jobs[nj].base = (char *)d.exit_coord_weights; jobs[nj].bytes = np*eff->n_energies*sizeof(double); nj++; }
+		if (planes[k] != NULL && !pc_plane_pooled_ready(planes[k])) { jobs[nj].base = planes[k]; jobs[nj].bytes = np*sizeof(double); nj++; }
+	if (d.exit_coord_weights != NULL && !pc_plane_pooled_ready(d.exit_coord_weights)) { jobs[nj].base = (char *)d.exit_coord_weights; jobs[nj].bytes = np*eff->n_energies*sizeof(double); nj++; }
+	if (nj == 0)
+		return;          /* every plane comes from the pool: faulted in and pinned already */
 	long cores = sysconf(_SC_NPROCESSORS_ONLN);
 	int nt = (int)(cores < 1 ? 1 : (cores > 16 ? 16 : cores));
 	pthread_t th[16];
@@ -217,6 +300,21 @@ void pc_transeff_prefault(polycap_transmission_efficiencies *eff, size_t np)
 	pc_touch_thread(&args[0]);
 	for (int t = 1; t < nt; t++)
 		if (started & (1 << t)) pthread_join(th[t], NULL);
+}
+
+/* the image fetch has pinned the (large) planes and left them pinned (option "keep_pinned"): remember it in their headers */
+void pc_transeff_planes_pinned(polycap_transmission_efficiencies *eff)
+{
+	if (eff == NULL || eff->images == NULL)
+		return;
+	pc_hip_images d;
+	pc_transeff_plane_pointers(eff, &d);
+	void *planes[] = { d.src_start_coords[0], d.src_start_coords[1], d.pc_start_coords[0], d.pc_start_coords[1],
+		d.pc_start_dir[0], d.pc_start_dir[1], d.pc_start_elecv[0], d.pc_start_elecv[1],
+		d.pc_exit_coords[0], d.pc_exit_coords[1], d.pc_exit_coords[2], d.pc_exit_dir[0], d.pc_exit_dir[1],
+		d.pc_exit_elecv[0], d.pc_exit_elecv[1], d.pc_exit_nrefl, d.pc_exit_dtravel, d.exit_coord_weights };
+	for (size_t k = 0; k < sizeof(planes)/sizeof(planes[0]); k++)
+		pc_plane_set_pinned(planes[k], 1);
 }
 
 /* totals -> open area, counts and efficiencies (reference: src/polycap-source.c:1061-1076) */
@@ -248,7 +346,7 @@ void *pc_transmission_efficiencies_from_totals(void *source_, int64_t n_exit, co
 		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "pc_transmission_efficiencies_from_totals: counters[0] must equal n_exit and at least one photon must have entered");
 		return NULL;
 	}
-	polycap_transmission_efficiencies *eff = pc_transeff_alloc(source, (size_t)n_exit, "pc_transmission_efficiencies_from_totals", error);
+	polycap_transmission_efficiencies *eff = pc_transeff_alloc(source, (size_t)n_exit, 1, "pc_transmission_efficiencies_from_totals", error);
 	if (eff == NULL)
 		return NULL;
 	if (planes != NULL && n_exit > 0) {

@@ -194,6 +194,16 @@ class TraceContext:
         planes[15] = nrefl
         return dict(planes=planes, exit_weights=w, nrefl=nrefl)
 
+    def slot_ids(self, first=0, count=None):
+        """Slot of the photon at positions [first, first+count) of the image planes of the last run: the identity, except
+        after a compact run (options compact_images + slot_ids), whose planes are in the order of completion."""
+        count = self._last_n - first if count is None else count
+        ids = np.zeros(count, dtype=np.int64)
+        st = self._L.pc_hip_transmission_slot_ids(self._h, int(first), int(count), ids.ctypes.data_as(c_int64_p))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_transmission_slot_ids", st)
+        return ids
+
     def transmission(self, seed, slot0, n_slots, max_attempts=1 << 20, keep_images=False, leak_calc=False):
         """run + wait + totals (+ images, + leak events) in one call."""
         self.run(seed, slot0, n_slots, max_attempts, keep_images, leak_calc)

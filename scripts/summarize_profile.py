@@ -1,4 +1,7 @@
-"""Condenses gpurun_out/prof_<tag>_* (rocprofv3 csv) into profiles/<round>/<tag>_*.{csv,json}:  python scripts/summarize_profile.py <tag> [round, default r02]"""
+"""Condenses gpurun_out/prof_<tag>_* (rocprofv3 csv) into profiles/<round>/<tag>_*.{csv,json}:
+    python scripts/summarize_profile.py <tag> [round, default r02] [--last]
+--last: the counters of the LAST dispatch of the trace kernel (commands whose earlier dispatches are small warm-up runs) instead
+of the average over its dispatches."""
 import collections
 import csv
 import glob
@@ -7,6 +10,9 @@ import os
 import shutil
 import sys
 
+last_only = "--last" in sys.argv
+if last_only:
+    sys.argv.remove("--last")
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(root, "profiles", sys.argv[2] if len(sys.argv) > 2 else "r02")
@@ -32,9 +38,10 @@ for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_%s_pmc*" % tag)
                 meta = dict(kernel=r["Kernel_Name"], VGPR=r["VGPR_Count"], SGPR=r["SGPR_Count"], LDS=r["LDS_Block_Size"],
                             grid=r["Grid_Size"], workgroup=r["Workgroup_Size"])
         for k, v in agg.items():
-            summary[k] = sum(v) / len(v)
+            summary[k] = v[-1] if last_only else sum(v) / len(v)
 summary["meta"] = meta
-summary["note"] = ("averages per dispatch of the trace kernel over bench.py's launches (1e7 exit-photon slots each); "
+summary["note"] = (("the last dispatch of the trace kernel in the profiled command (earlier ones are warm-up runs); " if last_only else
+                    "averages per dispatch of the trace kernel over bench.py's launches (1e7 exit-photon slots each); ") +
                    "FETCH_SIZE / WRITE_SIZE in KB as reported by rocprofv3, collected in separate --pmc passes")
 b = os.path.join(root, "gpurun_out", "bench_%s.json" % tag)
 if os.path.exists(b):

@@ -677,7 +677,7 @@ def test_c_api_multi_device_and_histogram_only(pa, monkeypatch):
     src = capi.Source.new_from_file(os.path.join(EXAMPLE, "xos1.inp"))
 
     def run(n, **env):
-        for k in ("POLYCAP_HIP_DEVICES", "POLYCAP_IMAGES", "POLYCAP_RCCL"):
+        for k in ("POLYCAP_HIP_DEVICES", "POLYCAP_IMAGES", "POLYCAP_RCCL", "POLYCAP_COMPACT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -687,8 +687,17 @@ def test_c_api_multi_device_and_histogram_only(pa, monkeypatch):
     b = run(200_000, POLYCAP_HIP_DEVICES="0,0")
     c = run(200_000, POLYCAP_HIP_DEVICES="0", POLYCAP_RCCL="1")
     assert np.array_equal(a.data[1], b.data[1]) and np.array_equal(a.data[1], c.data[1])
-    assert np.array_equal(a.exit_weights, b.exit_weights) and np.array_equal(a.n_refl, b.n_refl)
-    assert np.array_equal(a.d_travel, b.d_travel)
+    # the public call stores exit photons in the order of completion (compact store): the same photons, bit for bit, in another
+    # order -- put both in the order of the path length (distinct doubles) before comparing
+    ia, ib = np.argsort(a.d_travel, kind="stable"), np.argsort(b.d_travel, kind="stable")
+    assert np.array_equal(a.exit_weights[ia], b.exit_weights[ib]) and np.array_equal(a.n_refl[ia], b.n_refl[ib])
+    assert np.array_equal(a.d_travel[ia], b.d_travel[ib])
+    # POLYCAP_COMPACT=0: every photon at the position of its slot, so even the order is the same
+    a0, b0 = run(200_000, POLYCAP_COMPACT="0"), run(200_000, POLYCAP_HIP_DEVICES="0,0", POLYCAP_COMPACT="0")
+    assert np.array_equal(a0.exit_weights, b0.exit_weights) and np.array_equal(a0.d_travel, b0.d_travel)
+    i0 = np.argsort(a0.d_travel, kind="stable")
+    assert np.array_equal(a0.exit_weights[i0], a.exit_weights[ia]) and np.array_equal(a0.n_refl[i0], a.n_refl[ia])
+    del a0, b0
     h = run(200_000, POLYCAP_HIP_DEVICES="0,0", POLYCAP_IMAGES="0")
     assert np.array_equal(a.data[1], h.data[1])
     with pytest.raises(ValueError):
