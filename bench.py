@@ -5,7 +5,8 @@ One "step" = one pass of the hot path over one batch: polycap_source_get_transmi
 --photons exit-photon slots per GPU (default 1e7 = BASELINE config C2) on the xos1 optic at 10 keV, image planes
 kept in HBM, followed by the one RCCL all-reduce of the per-energy histogram.  Inputs (profile tables, optical
 constants, source parameters) are resident in HBM before the timed region; outputs (totals and the 18 image planes of
-struct _polycap_images, written by the kernel itself) stay in HBM.
+struct _polycap_images, written by the kernel itself in coalesced runs: the photons a wave finalises together take the next
+free positions of the planes) stay in HBM.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -40,7 +41,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0   # CUs x SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz
 # rocprofv3 --pmc passes of this same command, condensed by scripts/summarize_profile.py (profiles/README)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "headline_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "headline_pmc_summary.json")
 BYTES_PER_EXIT_PHOTON = 17 * 8   # 17 image planes of 8 B; + 8 B per energy for exit_coord_weights
 
 
@@ -117,6 +118,7 @@ def main():
     keep_images = not args.no_images
     ctx = polycap_amd.TraceContext(prob, dev_index)
     ctx.set_option("plane_images", 1)     # the image layout polycap_source_get_transmission_efficiencies runs with (planes, not records)
+    ctx.set_option("compact_images", 1)   # ... and its store: exit photons in the order of completion, coalesced runs per plane
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))

@@ -94,6 +94,8 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
  *                      threads with random seeds happen to fill them) -- and the planes are published in blocks of
  *                      2^"block_shift" positions (default 18) while the kernel runs: pc_hip_transmission_images copies a block
  *                      as soon as it is complete.  The set of photons is the same as with 0 (default), bit for bit.
+ *   "keep_pinned"      pc_hip_transmission_images leaves the destination planes it pinned (hipHostRegister) pinned: the
+ *                      caller reuses them for later runs and unpins them with pc_hip_host_unregister before freeing them
  *   "slot_ids"         compact runs also record which slot sits at which position (pc_hip_transmission_slot_ids)
  *   "batch_reflections" many-energy source runs: sweep a photon's weights once per four reflections (default 1)
  *   "fetch_threads"    host threads of the staging fallback of the image fetch (0 = min(16, cores))
@@ -135,6 +137,8 @@ POLYCAP_EXTERN int pc_hip_transmission_images(pc_hip_ctx *ctx, int64_t first, in
  * records: [count][PC_HIP_N_PLANES + n_energies]. */
 #define PC_HIP_N_PLANES 17
 POLYCAP_EXTERN int pc_hip_transmission_records(pc_hip_ctx *ctx, int64_t first, int64_t count, double *records);
+/* Unpins host memory that a fetch with option "keep_pinned" left pinned. */
+POLYCAP_EXTERN void pc_hip_host_unregister(void *ptr);
 /* Slot (relative to slot0 of the last run) of the photon stored at positions [first, first+count) of the image planes:
  * the identity unless the run was compact ("compact_images" with "slot_ids"). */
 POLYCAP_EXTERN int pc_hip_transmission_slot_ids(pc_hip_ctx *ctx, int64_t first, int64_t count, int64_t *slots);

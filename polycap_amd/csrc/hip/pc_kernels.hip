@@ -44,7 +44,9 @@
 #endif
 #define PC_KE 5                /* energies per lane whose weights are in flight together in a cooperative sweep */
 #ifndef PC_KB
-#define PC_KB 4                /* reflections of a photon that wait for one sweep of its weights (many-energy kernel) */
+#define PC_KB 5                /* reflections of a photon that wait for one sweep of its weights (many-energy kernel): 120 B of LDS per lane.
+                                * xos1 291 energies 1e6 slots / ellip_l9 291 sig 5 A 5e5 / xos1 100 energies, kernel ms: 4: 42.3 / 28.7 / 18.3,
+                                * 5: 38.9 / 27.9 / 16.8 (scripts/ab_ne3.sh; 6 does not fit next to the tables) */
 #endif
 #ifndef PC_SWEEP_IL
 #define PC_SWEEP_IL 1          /* (photon, energy) items a lane has in flight together in the flat sweep of the many-energy kernel */
@@ -403,11 +405,12 @@ pc_trace_kernel(pc_kargs a)
 #pragma unroll
 				for (int il = 0; il < IL; il++) {
 					const bool ok = r < n[il];
+					if (IL == 1 && !ok) continue;        /* one item per lane: lanes without this reflection sit it out (with more items the loop is branch-free) */
 					const double ct = gq[il][3*r], es2 = gq[il][3*r + 1], sd2 = gq[il][3*r + 2];
 					double rt;
 					const double f = pc_fresnel_fast<ROUGH>(n_re[il], n_im[il], a_re[il], a_im[il], rgh[il], ct, fma(-ct, ct, 1.0), es2, sd2 - es2, sd2, rt);
 					odd[il] |= ok && ((unsigned long long)__double_as_longlong(rt) > 0x3FF0000000000000ull);   /* negative, above 1 or NaN: looked at below */
-					w[il] = w[il]*(ok ? f : 1.0);
+					w[il] = w[il]*((IL == 1 || ok) ? f : 1.0);
 					cnt[il] += (ok && w[il] >= 1.e-4) ? 1u : 0u;
 				}
 			}
@@ -1088,6 +1091,7 @@ struct pc_hip_ctx {
 	 * plane and batch, and the planes are published block by block while the kernel runs (pc_kargs::img_cursor) */
 	int compact_images = 0;
 	int run_compact = 0;                   /* the last run did so */
+	int keep_pinned = 0;                   /* option "keep_pinned": pc_hip_transmission_images leaves the destination planes pinned */
 	int slot_ids = 0;                      /* option "slot_ids": compact runs also store which slot sits at which position */
 	int blk_shift = 18;                    /* option "block_shift": published blocks of 2^blk_shift positions (262144: 2 MB per plane) */
 	int run_blk_shift = 18;
@@ -1405,6 +1409,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "plane_images") ctx->plane_images = value ? 1 : 0;
 	else if (n == "compact_images") ctx->compact_images = value ? 1 : 0;
 	else if (n == "slot_ids") ctx->slot_ids = value ? 1 : 0;
+	else if (n == "keep_pinned") ctx->keep_pinned = value ? 1 : 0;
 	else if (n == "block_shift") { if (value < 7 || value > 30) return pc_fail(PC_HIP_ERR_INVALID, "block_shift must be in [7,30]"); ctx->blk_shift = (int)value; }
 	else if (n == "run_parts") { if (value < 1 || value > PC_MAX_PARTS) return pc_fail(PC_HIP_ERR_INVALID, "run_parts must be in [1,16]"); ctx->run_parts = (int)value; }
 	else if (n == "fetch_threads") { if (value < 0 || value > 256) return pc_fail(PC_HIP_ERR_INVALID, "fetch_threads must be in [0,256]"); ctx->fetch_threads = (int)value; }
@@ -1939,7 +1944,9 @@ static int pc_fetch_planes_direct(pc_hip_ctx *ctx, int64_t first, int64_t count,
 		void *p = (k < PC_N_FIELDS) ? planes[k] : (void *)weights;
 		if (!p) continue;
 		const size_t bytes = (size_t)count*sizeof(double)*(k < PC_N_FIELDS ? 1 : ne);
-		if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+		const hipError_t re = hipHostRegister(p, bytes, hipHostRegisterDefault);
+		if (re == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); continue; }      /* pinned by an earlier call (option keep_pinned) */
+		if (re != hipSuccess) {
 			(void)hipGetLastError();
 			if (ctx->run_planes) continue;        /* planes are all there is: this destination is copied unpinned (slower, still right) */
 			unpin();
@@ -2016,6 +2023,7 @@ static int pc_fetch_planes_direct(pc_hip_ctx *ctx, int64_t first, int64_t count,
 	if (hipStreamSynchronize(ctx->fetch_stream) != hipSuccess && status == PC_HIP_OK)
 		status = pc_fail(PC_HIP_ERR_RUNTIME, "pc_hip_transmission_images: the plane copies failed");
 	const double t_copied = now_ms();
+	if (ctx->keep_pinned) pinned.clear();      /* the caller keeps its planes pinned (and unpins them itself: pc_hip_host_unregister) */
 	unpin();
 	if (timing)
 		fprintf(stderr, "polycap timing [ms]: plane fetch: pin %.1f, enqueue %.1f, wait for trace + copies %.1f, unpin %.1f\n",
@@ -2160,6 +2168,11 @@ void pc_hip_efficiencies(size_t n_energies, const double *sum_weights, const int
 	double open_area = (double)(sum_iexit+sum_not_transmitted)/(sum_iexit+sum_not_entered+sum_not_transmitted);
 	for (size_t i = 0; i < n_energies; i++)
 		efficiencies[i] = (sum_weights[i] / ((double)sum_iexit+(double)sum_not_transmitted)) * open_area;
+}
+
+void pc_hip_host_unregister(void *ptr)
+{
+	if (ptr && hipHostUnregister(ptr) != hipSuccess) (void)hipGetLastError();
 }
 
 int pc_hip_device_synchronize(pc_hip_ctx *ctx)

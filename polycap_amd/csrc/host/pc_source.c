@@ -478,8 +478,15 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 		t_stage[3] = pc_now_ms();
 		pc_hip_images dst;
 		pc_transeff_plane_pointers(eff, &dst);
+		if (group == NULL)
+			(void)pc_hip_set_option(ctx, "keep_pinned", 1);      /* the planes stay pinned while the result lives and in the pool after it */
 		status = (group != NULL) ? pc_hip_group_images(group, &dst)
-		                         : pc_hip_transmission_images(ctx, 0, n_photons, &dst);    /* waits part by part (a leak run: for all of it) */
+		                         : pc_hip_transmission_images(ctx, 0, n_photons, &dst);    /* block by block behind the kernel (a leak run: after it) */
+		if (group == NULL) {
+			(void)pc_hip_set_option(ctx, "keep_pinned", 0);
+			if (status == PC_HIP_OK)
+				pc_transeff_planes_pinned(eff);      /* (a plane the fetch could not pin is unpinned in vain later: harmless) */
+		}
 	}
 	t_stage[4] = pc_now_ms();
 	int reduced_by = 0;
