@@ -92,8 +92,8 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
  *                      at the position of their slot -- the photons a wave finalises together are one coalesced run per plane
  *                      (the reference's order of photons in its arrays is as arbitrary: it is the order in which OpenMP
  *                      threads with random seeds happen to fill them) -- and the planes are published in blocks of
- *                      2^"block_shift" positions (default 18) while the kernel runs: pc_hip_transmission_images copies a block
- *                      as soon as it is complete.  The set of photons is the same as with 0 (default), bit for bit.
+ *                      2^"block_shift" positions (default 16) while the kernel runs: pc_hip_transmission_images copies the
+ *                      blocks that are complete, as many at a time as have piled up.  The set of photons is the same as with 0 (default), bit for bit.
  *   "keep_pinned"      pc_hip_transmission_images leaves the destination planes it pinned (hipHostRegister) pinned: the
  *                      caller reuses them for later runs and unpins them with pc_hip_host_unregister before freeing them
  *   "slot_ids"         compact runs also record which slot sits at which position (pc_hip_transmission_slot_ids)
@@ -178,6 +178,8 @@ POLYCAP_EXTERN void pc_hip_group_destroy(pc_hip_group *group);
 POLYCAP_EXTERN int pc_hip_group_size(const pc_hip_group *group);
 POLYCAP_EXTERN int pc_hip_group_set_option(pc_hip_group *group, const char *name, int64_t value);
 POLYCAP_EXTERN int pc_hip_group_run(pc_hip_group *group, uint64_t seed, int64_t n_slots, uint32_t max_attempts, int keep_images);
+/* kernel that traced member k's share of the last run (as pc_hip_last_kernel) */
+POLYCAP_EXTERN int pc_hip_group_last_kernel(pc_hip_group *group, int k);
 /* image planes of all n_slots slots of the last run (one host thread per member copies its range into dst) */
 POLYCAP_EXTERN int pc_hip_group_images(pc_hip_group *group, const pc_hip_images *dst);
 /* totals as pc_hip_transmission_totals; *reduced_by (optional) = 1 when the sum was made by RCCL, 0 on the host;

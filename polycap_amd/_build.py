@@ -21,7 +21,7 @@ LIB = os.path.join(LIBDIR, "libpolycap.so")
 HOST_SRCS = ["pc_error.c", "pc_rng.c", "pc_profile.c", "pc_description.c", "pc_optconst.c",
              "pc_photon.c", "pc_source.c", "pc_transeff.c", "pc_hdf5.c"]
 HIP_SRCS = ["pc_kernels.hip"]
-HIP_DEPS = ["pc_device.h", "pc_problem.h", "pc_leak.h", "pc_leak_kernels.h", "pc_pool_kernel.h", "pc_producer_kernel.h", "pc_group.h"]
+HIP_DEPS = ["pc_device.h", "pc_problem.h", "pc_leak.h", "pc_leak_kernels.h", "pc_pool_kernel.h", "pc_producer_kernel.h", "pc_wave_kernel.h", "pc_group.h"]
 
 CFLAGS = ["-std=c11", "-O2", "-fPIC", "-Wall", "-Wextra", "-fvisibility=hidden", "-I" + INC, "-I" + HOST]
 # -ffp-contract=off: fused multiply-adds appear only where pc_device.h writes fma() explicitly, so the device

@@ -158,6 +158,8 @@ def lib():
     L.pc_hip_group_set_option.restype = C.c_int
     L.pc_hip_group_run.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_uint32, C.c_int]
     L.pc_hip_group_run.restype = C.c_int
+    L.pc_hip_group_last_kernel.argtypes = [C.c_void_p, C.c_int]
+    L.pc_hip_group_last_kernel.restype = C.c_int
     L.pc_hip_group_images.argtypes = [C.c_void_p, P(ImagesS)]
     L.pc_hip_group_images.restype = C.c_int
     L.pc_hip_group_totals.argtypes = [C.c_void_p, C.c_int, c_double_p, c_int64_p, P(C.c_uint64), P(C.c_int), P(C.c_float)]

@@ -23,11 +23,12 @@ struct pc_rccl_api {
 	const char *(*GetErrorString)(int) = nullptr;
 };
 static pc_rccl_api g_rccl;
+static std::once_flag g_rccl_once;
 static const int PC_NCCL_INT64 = 4, PC_NCCL_SUM = 0;   /* ncclInt64, ncclSum (rccl.h) */
 
 static bool pc_rccl_available()
 {
-	if (!g_rccl.probed) {
+	std::call_once(g_rccl_once, []() {
 		g_rccl.probed = 1;
 		const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", nullptr };
 		for (int i = 0; names[i] && !g_rccl.handle; i++)
@@ -44,7 +45,7 @@ static bool pc_rccl_available()
 				g_rccl.handle = nullptr;
 			}
 		}
-	}
+	});
 	return g_rccl.handle != nullptr;
 }
 
@@ -139,18 +140,55 @@ int pc_hip_group_run(pc_hip_group *g, uint64_t seed, int64_t n_slots, uint32_t m
 {
 	if (!g) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_group_run: group must not be NULL");
 	if (n_slots < 1) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_group_run: n_slots must be >= 1");
-	const long long N = (long long)g->ctx.size();
+	const size_t N = g->ctx.size();
 	g->run_slots = n_slots;
 	g->keep_images = keep_images ? 1 : 0;
-	for (long long k = 0; k < N; k++) {
+	/* One measure of the photons' lifetime decides the kernel for every member: the first member's previous run, or a probe on
+	 * it (3 ms, once per group) when the WHOLE run is big -- a member's share of it may well be below the size from which a
+	 * context probes by itself (1e7 slots over 8 devices), and eight probes one after the other would serialise the enqueue. */
+	{
+		pc_hip_ctx *c0 = g->ctx[0];
+		if (c0->producer < 0 && c0->refl_per_launch < 0. && c0->host.pm.n_energies == 1 && n_slots >= 2000000) {
+			if (max_attempts < 1) max_attempts = 1;
+			int st = pc_probe_lifetime(c0, seed, 0, max_attempts);
+			if (st) return st;
+		}
+		for (size_t k = 1; k < N; k++)
+			if (g->ctx[k]->refl_per_launch < 0.) g->ctx[k]->refl_per_launch = c0->refl_per_launch;
+	}
+	for (size_t k = 0; k < N; k++) {
 		/* contiguous ranges that differ by at most one slot */
-		const long long lo = (long long)((__int128)n_slots*k/N), hi = (long long)((__int128)n_slots*(k + 1)/N);
+		const long long lo = (long long)((__int128)n_slots*(long long)k/(long long)N), hi = (long long)((__int128)n_slots*(long long)(k + 1)/(long long)N);
 		g->first[k] = lo; g->count[k] = hi - lo;
-		if (hi == lo) continue;
-		int st = pc_hip_transmission_run(g->ctx[k], seed, lo, hi - lo, max_attempts, keep_images);
-		if (st) return st;
+	}
+	/* every member is enqueued from a host thread of its own (hipSetDevice is per thread) */
+	std::vector<int> status(N, PC_HIP_OK);
+	std::vector<std::string> msg(N);
+	auto enqueue = [&](size_t k) {
+		if (g->count[k] == 0) return;
+		status[k] = pc_hip_transmission_run(g->ctx[k], seed, g->first[k], g->count[k], max_attempts, keep_images);
+		if (status[k]) msg[k] = g_last_error;       /* the error text is per thread */
+	};
+	{
+		std::vector<std::thread> th;
+		for (size_t k = 1; k < N; k++) th.emplace_back(enqueue, k);
+		enqueue(0);
+		for (auto &t : th) t.join();
+	}
+	for (size_t k = 0; k < N; k++) {
+		if (status[k] == PC_HIP_OK) continue;
+		/* a member failed: the others are waited for, so that nothing of this run is pending when the error is reported */
+		for (size_t j = 0; j < N; j++)
+			if (g->ctx[j]->run_pending) (void)pc_hip_transmission_wait(g->ctx[j], nullptr);
+		return pc_fail(status[k], msg[k]);
 	}
 	return PC_HIP_OK;
+}
+
+/* kernel that traced member k's share of the last run (pc_hip_last_kernel) */
+int pc_hip_group_last_kernel(pc_hip_group *g, int k)
+{
+	return (g && k >= 0 && (size_t)k < g->ctx.size()) ? g->ctx[(size_t)k]->last_kernel : -1;
 }
 
 int pc_hip_group_images(pc_hip_group *g, const pc_hip_images *dst)
@@ -180,10 +218,42 @@ int pc_hip_group_images(pc_hip_group *g, const pc_hip_images *dst)
 		status[k] = pc_hip_transmission_images(g->ctx[k], 0, g->count[k], &d);
 		if (status[k]) msg[k] = g_last_error;       /* the error text is per thread */
 	};
+	/* The destination planes are pinned here, once and whole: the members' sub-ranges share pages at their boundaries, and
+	 * a member that pinned and unpinned its own range would unpin a neighbour's first page under its running copy (the members
+	 * find their ranges pinned already and leave them alone). */
+	std::vector<void *> pinned;
+	bool all_pinned = N > 1;
+	if (N > 1) {
+		void *planes[PC_N_FIELDS + 1] = {
+			dst->src_start_coords[0], dst->src_start_coords[1], dst->pc_start_coords[0], dst->pc_start_coords[1],
+			dst->pc_start_dir[0], dst->pc_start_dir[1], dst->pc_start_elecv[0], dst->pc_start_elecv[1],
+			dst->pc_exit_coords[0], dst->pc_exit_coords[1], dst->pc_exit_coords[2],
+			dst->pc_exit_dir[0], dst->pc_exit_dir[1], dst->pc_exit_elecv[0], dst->pc_exit_elecv[1],
+			dst->pc_exit_nrefl, dst->pc_exit_dtravel, dst->exit_coord_weights };
+		(void)hipSetDevice(g->devices[0]);
+		for (int f = 0; f <= PC_N_FIELDS; f++) {
+			if (!planes[f]) continue;
+			const size_t bytes = (size_t)g->run_slots*sizeof(double)*(f < PC_N_FIELDS ? 1 : ne);
+			const hipError_t re = pc_host_is_pinned(planes[f]) ? hipErrorHostMemoryAlreadyRegistered : hipHostRegister(planes[f], bytes, hipHostRegisterPortable);
+			if (re == hipSuccess) pinned.push_back(planes[f]);
+			else {
+				(void)hipGetLastError();
+				if (re != hipErrorHostMemoryAlreadyRegistered) all_pinned = false;
+			}
+		}
+		if (!all_pinned) {
+			/* some plane could not be pinned: nothing is, and the members copy through their own (slower) paths */
+			for (void *p : pinned) (void)hipHostUnregister(p);
+			pinned.clear();
+		}
+	}
+	for (pc_hip_ctx *c : g->ctx) c->dst_prepinned = all_pinned ? 1 : 0;
 	std::vector<std::thread> th;
 	for (size_t k = 1; k < N; k++) th.emplace_back(fetch, k);
 	fetch(0);
 	for (auto &t : th) t.join();
+	for (pc_hip_ctx *c : g->ctx) c->dst_prepinned = 0;
+	for (void *p : pinned) (void)hipHostUnregister(p);
 	for (size_t k = 0; k < N; k++)
 		if (status[k]) return pc_fail(status[k], msg[k]);
 	return PC_HIP_OK;

@@ -878,6 +878,7 @@ pc_trace_kernel(pc_kargs a)
 
 #include "pc_pool_kernel.h"
 #include "pc_producer_kernel.h"
+#include "pc_wave_kernel.h"
 
 /* Image records (one contiguous record of 17 + n_energies doubles per slot) -> the planes of struct _polycap_images: 17
  * planes of n_total doubles each, then the weights as [slot][n_energies].  A workgroup stages PC_SOA_TILE records in LDS
@@ -1049,6 +1050,7 @@ struct pc_hip_ctx {
 	int last_kernel = -1;          /* pc_hip_last_kernel */
 	int last_run_plain = 0;        /* the last run was pc_hip_transmission_run (its counters tell refl_per_launch) */
 	int producer_new_min = 2, producer_new_first = 6;
+	int wave_per_photon = 0;       /* EXPERIMENT (pc_wave_kernel.h): 1 = single-energy histogram-only source runs with one wave per photon */
 	int pool = 0;                  /* 1: single-energy source runs on profiles of up to 1024 points use the per-wave photon pool in LDS (pc_pool_kernel.h).
 	                                * Was the default up to v14 (+6 %); since flights take 5.5 steps instead of 8.8 the exchanges with the pool cost more
 	                                * than its fuller phases save (26.3 ms against 23.3 ms for the one-photon-per-lane kernel) */
@@ -1068,6 +1070,8 @@ struct pc_hip_ctx {
 	bool h_stage_pinned = false;           /* false: pinning was refused (locked-memory limit), plain memory is used instead */
 	hipEvent_t ev_fetch[2] = {nullptr, nullptr};
 	hipStream_t fetch_stream = nullptr;    /* copies of finished parts run beside the kernel of the next part */
+	hipStream_t fetch_stream_b = nullptr;  /* compact runs: the planes of a group of blocks alternate between two copy streams */
+	hipEvent_t ev_group[2][4] = {{nullptr}};   /* compact runs: end of a group of copies, per stream, ring of 4 */
 	hipStream_t stream2 = nullptr;         /* odd parts: a part's first workgroups start as the previous part's last ones leave */
 	unsigned long long *d_work = nullptr;  /* one work counter per part */
 	hipEvent_t ev_sync = nullptr;
@@ -1091,10 +1095,12 @@ struct pc_hip_ctx {
 	 * plane and batch, and the planes are published block by block while the kernel runs (pc_kargs::img_cursor) */
 	int compact_images = 0;
 	int run_compact = 0;                   /* the last run did so */
+	int dst_prepinned = 0;                 /* the caller (a device group) has pinned the destination planes itself: the fetch pins nothing */
 	int keep_pinned = 0;                   /* option "keep_pinned": pc_hip_transmission_images leaves the destination planes pinned */
 	int slot_ids = 0;                      /* option "slot_ids": compact runs also store which slot sits at which position */
-	int blk_shift = 18;                    /* option "block_shift": published blocks of 2^blk_shift positions (262144: 2 MB per plane) */
-	int run_blk_shift = 18;
+	int blk_shift = 16;                    /* option "block_shift": published blocks of 2^blk_shift positions (65536: 512 KB per plane; the fetch
+	                                        * copies all the blocks that are complete at a time in one go) */
+	int run_blk_shift = 16;
 	long long run_blocks = 0;
 	unsigned long long *d_cursor = nullptr;
 	unsigned int *d_blk_done = nullptr;
@@ -1215,6 +1221,19 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 	a.lds_pend = (a.lds_ec && ne > 32 && ctx->batch_reflections && all_valid && MODE != PC_MODE_EXPLICIT) ? 1 : 0;   /* source runs only: an explicit
 	                                       * photon reports its state at the absorbing reflection, which the speculation overwrites */
 	if constexpr (MODE != PC_MODE_EXPLICIT) {
+		if (ctx->wave_per_photon && ne == 1 && !a.keep_images && ctx->host.pm.nmax + 1 <= 1024) {
+			/* the experiment of pc_wave_kernel.h: one wave per photon, 16 waves per CU */
+			long long want = (n_items + 3) / 4;
+			int grid = (int)(want < 4ll*ctx->n_cu ? want : 4ll*ctx->n_cu);
+			if (grid < 1) grid = 1;
+			a.total_threads = (long long)grid * PCW_BLOCK;
+			if (ctx->rec_ev0) PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+			hipLaunchKernelGGL((pc_trace_wave_kernel<MODE>), dim3(grid), dim3(PCW_BLOCK), 0, ctx->stream, a);
+			ctx->last_kernel = 3;
+			PC_HIP_CHECK(hipGetLastError());
+			if (ctx->rec_ev1) PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+			return PC_HIP_OK;
+		}
 		const pc_params &pm = ctx->host.pm;
 		const bool want_producer = ctx->producer == 1 || (ctx->producer < 0 && !ctx->in_probe && ctx->refl_per_launch >= PC3_MIN_REFL);
 		if (want_producer && pm.n_energies == 1 && !ctx->literal && pm.nmax + 1 <= PC3_PITCH && a.max_attempts <= (1u << 24)
@@ -1314,6 +1333,8 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	for (int k = 0; k < 2; k++) if (ctx->ev_fetch[k]) (void)hipEventDestroy(ctx->ev_fetch[k]);
 	for (int k = 0; k < PC_MAX_PARTS; k++) if (ctx->ev_part[k]) (void)hipEventDestroy(ctx->ev_part[k]);
 	if (ctx->fetch_stream) (void)hipStreamDestroy(ctx->fetch_stream);
+	if (ctx->fetch_stream_b) (void)hipStreamDestroy(ctx->fetch_stream_b);
+	for (int k = 0; k < 2; k++) for (int j = 0; j < 4; j++) if (ctx->ev_group[k][j]) (void)hipEventDestroy(ctx->ev_group[k][j]);
 	if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
 	if (ctx->d_work) (void)hipFree(ctx->d_work);
 	if (ctx->ev_sync) (void)hipEventDestroy(ctx->ev_sync);
@@ -1414,6 +1435,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "run_parts") { if (value < 1 || value > PC_MAX_PARTS) return pc_fail(PC_HIP_ERR_INVALID, "run_parts must be in [1,16]"); ctx->run_parts = (int)value; }
 	else if (n == "fetch_threads") { if (value < 0 || value > 256) return pc_fail(PC_HIP_ERR_INVALID, "fetch_threads must be in [0,256]"); ctx->fetch_threads = (int)value; }
 	else if (n == "pool") ctx->pool = value ? 1 : 0;
+	else if (n == "wave_per_photon") ctx->wave_per_photon = value ? 1 : 0;
 	else if (n == "producer") { if (value < -1 || value > 1) return pc_fail(PC_HIP_ERR_INVALID, "producer must be -1 (automatic), 0 or 1"); ctx->producer = (int)value; }
 	else if (n == "producer_new_min") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "producer_new_min must be in [1,64]"); ctx->producer_new_min = (int)value; }
 	else if (n == "producer_new_first") { if (value < 1 || value > 65) return pc_fail(PC_HIP_ERR_INVALID, "producer_new_first must be in [1,65]"); ctx->producer_new_first = (int)value; }
@@ -1626,6 +1648,18 @@ static long long pc_part_begin(long long n_slots, int parts, int k)
 /* image planes: 17 double-sized planes of n_slots entries followed by the weights plane */
 static const int PC_N_PLANES = 17;
 
+/* How long do photons live on this optic?  32768 slots with the default kernel (3 ms, results unused) set refl_per_launch, by
+ * which the context -- or, for a device group, every member -- picks the kernel of its source runs. */
+static int pc_probe_lifetime(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, uint32_t max_attempts)
+{
+	ctx->in_probe = 1;
+	int64_t c[6];
+	int st = pc_hip_transmission_run(ctx, seed, slot0, 32768, max_attempts, 0);
+	if (st == PC_HIP_OK) st = pc_hip_transmission_totals(ctx, nullptr, c, nullptr);
+	ctx->in_probe = 0;
+	return (st == PC_HIP_ERR_ATTEMPTS) ? PC_HIP_OK : st;
+}
+
 /* buffers of a compact run of n_slots (pc_kargs::img_cursor): position counter, per-block counters, the host-visible block
  * flags, the lanes' start-image lines and, on request, the plane of slot indices; counters and flags are cleared */
 static int pc_compact_prepare(pc_hip_ctx *ctx, long long n_slots)
@@ -1679,12 +1713,8 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 	const size_t ne = (size_t)ctx->host.pm.n_energies;
 	if (ctx->producer < 0 && ctx->refl_per_launch < 0. && !ctx->in_probe && ne == 1 && n_slots >= 2000000) {
 		/* first big run of the context: 32768 slots with the default kernel tell how long photons live here (3 ms, results unused) */
-		ctx->in_probe = 1;
-		int64_t c[6];
-		int st = pc_hip_transmission_run(ctx, seed, slot0, 32768, max_attempts, 0);
-		if (st == PC_HIP_OK) st = pc_hip_transmission_totals(ctx, nullptr, c, nullptr);
-		ctx->in_probe = 0;
-		if (st != PC_HIP_OK && st != PC_HIP_ERR_ATTEMPTS) return st;
+		int st = pc_probe_lifetime(ctx, seed, slot0, max_attempts);
+		if (st != PC_HIP_OK) return st;
 	}
 	ctx->last_run_plain = 1;
 	pc_kargs a;
@@ -1915,6 +1945,16 @@ int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6])
  * more context alive in the process the copies of a finished part landed in the queue of the next part's kernel and waited
  * for it (40 -> 54 ms per 1e7 photons through the C API, scripts/analysis/api_time2.py).  A stream of the highest priority
  * gets a queue of its own class, apart from the kernels' queues. */
+/* is this host address pinned already (an earlier fetch with "keep_pinned", a slab from the host pool, the caller's own
+ * hipHostRegister / hipHostMalloc)?  Pinning a range inside an existing registration a second time is not something to try. */
+static bool pc_host_is_pinned(void *p)
+{
+	unsigned int flags = 0;
+	if (hipHostGetFlags(&flags, p) == hipSuccess) return true;
+	(void)hipGetLastError();
+	return false;
+}
+
 static hipError_t pc_fetch_stream_ensure(pc_hip_ctx *ctx)
 {
 	if (ctx->fetch_stream) return hipSuccess;
@@ -1940,11 +1980,44 @@ static int pc_fetch_planes_direct(pc_hip_ctx *ctx, int64_t first, int64_t count,
 	/* pin the destinations */
 	std::vector<void *> pinned;
 	auto unpin = [&]() { for (void *p : pinned) (void)hipHostUnregister(p); pinned.clear(); };
-	for (int k = 0; k <= PC_N_FIELDS; k++) {
+	/* Planes at one common stride (polycap_source_get_transmission_efficiencies allocates its result as one slab): pinned in one
+	 * piece, and a group of blocks is ONE pitched copy of 17 (one energy: 18, the weights are the 18th plane) rows instead of as
+	 * many linear ones -- a copy costs the engine 4-5 us whatever its size (scripts/analysis/copy2d_probe.hip: 56.5 against
+	 * 49 GB/s at 0.5 M positions per group). */
+	long long slab_stride = 0;      /* bytes between two planes, 0: no common stride */
+	int slab_rows = 0;
+	const bool pin_here = !ctx->dst_prepinned;
+	if (ctx->run_compact && planes[0] && planes[1]) {
+		const long long st = (long long)((char *)planes[1] - (char *)planes[0]);
+		bool uniform = st >= (long long)((size_t)count*sizeof(double));
+		for (int f = 2; f < PC_N_FIELDS && uniform; f++)
+			uniform = planes[f] && (char *)planes[f] - (char *)planes[0] == (long long)f*st;
+		if (uniform) {
+			slab_stride = st;
+			slab_rows = PC_N_FIELDS;
+			if (ne == 1 && weights && (char *)weights - (char *)planes[0] == (long long)PC_N_FIELDS*st) slab_rows = PC_N_FIELDS + 1;
+		}
+	}
+	if (slab_stride && pin_here) {
+		const bool w_in = weights && (char *)weights - (char *)planes[0] == (long long)PC_N_FIELDS*slab_stride;
+		const size_t bytes = w_in ? (size_t)PC_N_FIELDS*(size_t)slab_stride + (size_t)count*ne*sizeof(double)
+		                          : (size_t)(PC_N_FIELDS - 1)*(size_t)slab_stride + (size_t)count*sizeof(double);
+		const hipError_t re = pc_host_is_pinned(planes[0]) ? hipErrorHostMemoryAlreadyRegistered : hipHostRegister(planes[0], bytes, hipHostRegisterDefault);
+		if (re == hipSuccess) pinned.push_back(planes[0]);
+		else {
+			(void)hipGetLastError();
+			if (re != hipErrorHostMemoryAlreadyRegistered) { slab_stride = 0; slab_rows = 0; }      /* plane by plane below */
+		}
+		if (slab_stride && weights && !w_in) {
+			const hipError_t rw = pc_host_is_pinned(weights) ? hipErrorHostMemoryAlreadyRegistered : hipHostRegister(weights, (size_t)count*ne*sizeof(double), hipHostRegisterDefault);
+			if (rw == hipSuccess) pinned.push_back(weights); else (void)hipGetLastError();
+		}
+	}
+	for (int k = 0; k <= PC_N_FIELDS && !slab_stride && pin_here; k++) {
 		void *p = (k < PC_N_FIELDS) ? planes[k] : (void *)weights;
 		if (!p) continue;
 		const size_t bytes = (size_t)count*sizeof(double)*(k < PC_N_FIELDS ? 1 : ne);
-		const hipError_t re = hipHostRegister(p, bytes, hipHostRegisterDefault);
+		const hipError_t re = pc_host_is_pinned(p) ? hipErrorHostMemoryAlreadyRegistered : hipHostRegister(p, bytes, hipHostRegisterDefault);
 		if (re == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); continue; }      /* pinned by an earlier call (option keep_pinned) */
 		if (re != hipSuccess) {
 			(void)hipGetLastError();
@@ -1961,11 +2034,31 @@ static int pc_fetch_planes_direct(pc_hip_ctx *ctx, int64_t first, int64_t count,
 		/* the kernel publishes its planes block by block (pc_blocks_written): every block is copied as soon as its flag is up,
 		 * while the kernel goes on.  The kernel's end also ends the wait (every block is complete then). */
 		const long long B = 1ll << ctx->run_blk_shift;
+		const long long b_end = std::min<long long>(ctx->run_blocks, (first + count + B - 1) >> ctx->run_blk_shift);
 		bool kernel_done = false;
-		for (long long b = first >> ctx->run_blk_shift; b < ctx->run_blocks && b*B < first + count && status == PC_HIP_OK; b++) {
-			volatile unsigned int *flag = ctx->h_blk_flag + b;
+		long long b = first >> ctx->run_blk_shift;
+		int group = 0;
+		/* POLYCAP_FETCH_STREAMS (1 or 2, default 2): copy streams the planes of a group alternate between; POLYCAP_FETCH_DEPTH
+		 * (1..3, default 2): groups of copies in flight */
+		int n_streams = 2, depth = 2;
+		if (const char *ev = getenv("POLYCAP_FETCH_STREAMS")) n_streams = (*ev == '1') ? 1 : 2;
+		if (const char *ev = getenv("POLYCAP_FETCH_DEPTH")) depth = (*ev >= '1' && *ev <= '3') ? *ev - '0' : 2;
+		if (n_streams == 2 && !ctx->fetch_stream_b) {
+			int least = 0, greatest = 0;
+			if (!(hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least
+			      && hipStreamCreateWithPriority(&ctx->fetch_stream_b, hipStreamNonBlocking, greatest) == hipSuccess)) {
+				(void)hipGetLastError();
+				PC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->fetch_stream_b, hipStreamNonBlocking));
+			}
+		}
+		for (int k = 0; k < 2; k++)
+			for (int j = 0; j < 4; j++)
+				if (!ctx->ev_group[k][j]) PC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_group[k][j], hipEventDisableTiming));
+		hipStream_t streams[2] = { ctx->fetch_stream, n_streams == 2 ? ctx->fetch_stream_b : ctx->fetch_stream };
+		while (b < b_end && status == PC_HIP_OK) {
+			volatile unsigned int *flag = ctx->h_blk_flag;
 			unsigned long spins = 0;
-			while (!kernel_done && *flag == 0u) {
+			while (!kernel_done && flag[b] == 0u) {
 				if ((++spins & 63ul) == 0ul) {
 					const hipError_t q = hipEventQuery(ctx->ev1);
 					if (q == hipSuccess) kernel_done = true;
@@ -1975,21 +2068,47 @@ static int pc_fetch_planes_direct(pc_hip_ctx *ctx, int64_t first, int64_t count,
 				std::this_thread::yield();
 			}
 			if (status != PC_HIP_OK) break;
+			/* `depth` groups of copies are kept in flight: the next one is put together when the oldest has finished, from every
+			 * block that is complete by then.  The first block is ready a fraction of a millisecond into the run; as the kernel
+			 * produces faster than PCIe carries, every group is larger than the one before (up to 64 blocks) and the copy engines
+			 * never wait -- nor are they fed thousands of small copies (4-5 us each, whatever their size). */
+			if (group >= depth) {
+				for (int k = 0; k < n_streams && status == PC_HIP_OK; k++) {
+					const hipError_t we = hipEventSynchronize(ctx->ev_group[k][(group - depth) & 3]);
+					if (we != hipSuccess) status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_transmission_images: ") + hipGetErrorString(we));
+				}
+				if (status != PC_HIP_OK) break;
+			}
+			long long e = b + 1;
+			while (e < b_end && e - b < 64 && (kernel_done || flag[e] != 0u)) e++;
 			std::atomic_thread_fence(std::memory_order_acquire);
-			const long long lo = std::max<long long>(b*B, first), hi = std::min<long long>(std::min<long long>((b + 1)*B, n_total), first + count);
-			hipError_t e = hipSuccess;
-			for (int f = 0; f <= PC_N_FIELDS && e == hipSuccess; f++) {
+			const long long lo = std::max<long long>(b*B, first), hi = std::min<long long>(std::min<long long>(e*B, n_total), first + count);
+			hipError_t err = hipSuccess;
+			if (slab_stride) {
+				err = hipMemcpy2DAsync((double *)planes[0] + (lo - first), (size_t)slab_stride, ctx->d_soa + lo, (size_t)n_total*sizeof(double),
+				                       (size_t)(hi - lo)*sizeof(double), (size_t)slab_rows, hipMemcpyDeviceToHost, streams[0]);
+				if (err == hipSuccess && weights && slab_rows == PC_N_FIELDS)
+					err = hipMemcpyAsync(weights + (size_t)(lo - first)*ne, ctx->d_soa + (size_t)PC_N_FIELDS*n_total + (size_t)lo*ne,
+					                     (size_t)(hi - lo)*ne*sizeof(double), hipMemcpyDeviceToHost, streams[1]);
+			}
+			for (int f = 0; f <= PC_N_FIELDS && err == hipSuccess && !slab_stride; f++) {
 				if (f < PC_N_FIELDS) {
 					if (!planes[f]) continue;
-					e = hipMemcpyAsync((double *)planes[f] + (lo - first), ctx->d_soa + (size_t)f*n_total + lo, (size_t)(hi - lo)*sizeof(double),
-					                   hipMemcpyDeviceToHost, ctx->fetch_stream);
+					err = hipMemcpyAsync((double *)planes[f] + (lo - first), ctx->d_soa + (size_t)f*n_total + lo, (size_t)(hi - lo)*sizeof(double),
+					                     hipMemcpyDeviceToHost, streams[f & 1]);
 				} else if (weights) {
-					e = hipMemcpyAsync(weights + (size_t)(lo - first)*ne, ctx->d_soa + (size_t)PC_N_FIELDS*n_total + (size_t)lo*ne,
-					                   (size_t)(hi - lo)*ne*sizeof(double), hipMemcpyDeviceToHost, ctx->fetch_stream);
+					err = hipMemcpyAsync(weights + (size_t)(lo - first)*ne, ctx->d_soa + (size_t)PC_N_FIELDS*n_total + (size_t)lo*ne,
+					                     (size_t)(hi - lo)*ne*sizeof(double), hipMemcpyDeviceToHost, streams[f & 1]);
 				}
 			}
-			if (e != hipSuccess) status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_transmission_images: ") + hipGetErrorString(e));
+			for (int k = 0; k < n_streams && err == hipSuccess; k++)
+				err = hipEventRecord(ctx->ev_group[k][group & 3], streams[k]);
+			if (err != hipSuccess) status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_transmission_images: ") + hipGetErrorString(err));
+			b = e;
+			group++;
 		}
+		if (n_streams == 2 && hipStreamSynchronize(ctx->fetch_stream_b) != hipSuccess && status == PC_HIP_OK)
+			status = pc_fail(PC_HIP_ERR_RUNTIME, "pc_hip_transmission_images: the plane copies failed");
 	}
 	for (int k = 0; k < parts && status == PC_HIP_OK; k++) {
 		const long long plo = (parts > 1 && k > 0) ? ctx->part_end[k - 1] : 0, phi = (parts > 1) ? ctx->part_end[k] : n_total;
@@ -2023,7 +2142,7 @@ static int pc_fetch_planes_direct(pc_hip_ctx *ctx, int64_t first, int64_t count,
 	if (hipStreamSynchronize(ctx->fetch_stream) != hipSuccess && status == PC_HIP_OK)
 		status = pc_fail(PC_HIP_ERR_RUNTIME, "pc_hip_transmission_images: the plane copies failed");
 	const double t_copied = now_ms();
-	if (ctx->keep_pinned) pinned.clear();      /* the caller keeps its planes pinned (and unpins them itself: pc_hip_host_unregister) */
+	if (ctx->keep_pinned && slab_stride) pinned.clear();      /* the caller keeps its slab pinned (and unpins it itself: pc_hip_host_unregister) */
 	unpin();
 	if (timing)
 		fprintf(stderr, "polycap timing [ms]: plane fetch: pin %.1f, enqueue %.1f, wait for trace + copies %.1f, unpin %.1f\n",

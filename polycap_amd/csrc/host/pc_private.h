@@ -94,6 +94,11 @@ struct _polycap_photon {
 };
 
 struct _polycap_images {
+	/* The 17 planes + the weights of a result with images are ONE allocation ("slab", pc_transeff.c): plane k at
+	 * slab + k*slab_stride bytes, in the order of pc_hip_images, the weights last -- so that the device's planes cross PCIe as
+	 * one pitched copy per group of blocks and the whole result is pinned in one piece.  NULL: every plane on its own. */
+	void *slab;
+	size_t slab_stride;
 	int64_t i_start;
 	int64_t i_exit;
 	double *src_start_coords[2];

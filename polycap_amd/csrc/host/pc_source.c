@@ -465,6 +465,8 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 		status = pc_hip_set_option(ctx, "run_parts", parts);
 		if (status == PC_HIP_OK)
 			status = pc_hip_set_option(ctx, "compact_images", compact);
+		if (status == PC_HIP_OK && getenv("POLYCAP_BLOCK_SHIFT") != NULL)
+			status = pc_hip_set_option(ctx, "block_shift", (int64_t)pc_env_u64("POLYCAP_BLOCK_SHIFT", 18, NULL));
 		if (status == PC_HIP_OK)
 			status = pc_hip_set_option(ctx, "plane_images", leak_calc ? 0 : 1);   /* the result object wants planes: let the kernel write them */
 		if (status == PC_HIP_OK)
@@ -478,14 +480,16 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 		t_stage[3] = pc_now_ms();
 		pc_hip_images dst;
 		pc_transeff_plane_pointers(eff, &dst);
-		if (group == NULL)
-			(void)pc_hip_set_option(ctx, "keep_pinned", 1);      /* the planes stay pinned while the result lives and in the pool after it */
+		/* a result in one slab stays pinned while it lives and in the pool after it (pc_transeff.c); planes of their own are
+		 * pinned for the call only */
+		const int keep_pinned = (group == NULL && eff->images->slab != NULL);
+		if (keep_pinned)
+			(void)pc_hip_set_option(ctx, "keep_pinned", 1);
 		status = (group != NULL) ? pc_hip_group_images(group, &dst)
 		                         : pc_hip_transmission_images(ctx, 0, n_photons, &dst);    /* block by block behind the kernel (a leak run: after it) */
-		if (group == NULL) {
+		if (keep_pinned) {
 			(void)pc_hip_set_option(ctx, "keep_pinned", 0);
-			if (status == PC_HIP_OK)
-				pc_transeff_planes_pinned(eff);      /* (a plane the fetch could not pin is unpinned in vain later: harmless) */
+			pc_transeff_planes_pinned(eff);      /* also after a failure: what the fetch pinned stays pinned until the slab is freed */
 		}
 	}
 	t_stage[4] = pc_now_ms();

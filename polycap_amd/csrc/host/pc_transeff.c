@@ -143,6 +143,15 @@ static void pc_images_free(struct _polycap_images *images)
 {
 	if (images == NULL)
 		return;
+	if (images->slab != NULL) {
+		/* the planes are parts of the slab */
+		pc_plane_free(images->slab);
+		memset(images->src_start_coords, 0, sizeof(images->src_start_coords)); memset(images->pc_start_coords, 0, sizeof(images->pc_start_coords));
+		memset(images->pc_start_dir, 0, sizeof(images->pc_start_dir)); memset(images->pc_start_elecv, 0, sizeof(images->pc_start_elecv));
+		memset(images->pc_exit_coords, 0, sizeof(images->pc_exit_coords)); memset(images->pc_exit_dir, 0, sizeof(images->pc_exit_dir));
+		memset(images->pc_exit_elecv, 0, sizeof(images->pc_exit_elecv));
+		images->pc_exit_nrefl = NULL; images->pc_exit_dtravel = NULL; images->exit_coord_weights = NULL;
+	}
 	for (int k = 0; k < 2; k++) {
 		pc_plane_free(images->src_start_coords[k]);
 		pc_plane_free(images->pc_start_coords[k]);
@@ -202,18 +211,35 @@ polycap_transmission_efficiencies *pc_transeff_alloc(polycap_source *source, siz
 		struct _polycap_images *im = eff->images;
 		eff->energies = malloc(sizeof(double)*ne);
 		eff->efficiencies = malloc(sizeof(double)*ne);
+		/* the planes in the order of pc_hip_images (pc_transeff_plane_pointers): the order the device keeps them in */
 		double **planes[] = { &im->src_start_coords[0], &im->src_start_coords[1], &im->pc_start_coords[0], &im->pc_start_coords[1],
 			&im->pc_start_dir[0], &im->pc_start_dir[1], &im->pc_start_elecv[0], &im->pc_start_elecv[1],
 			&im->pc_exit_coords[0], &im->pc_exit_coords[1], &im->pc_exit_coords[2],
-			&im->pc_exit_dir[0], &im->pc_exit_dir[1], &im->pc_exit_elecv[0], &im->pc_exit_elecv[1], &im->pc_exit_dtravel };
+			&im->pc_exit_dir[0], &im->pc_exit_dir[1], &im->pc_exit_elecv[0], &im->pc_exit_elecv[1], NULL /* nrefl */, &im->pc_exit_dtravel };
+		const size_t nplanes = sizeof(planes)/sizeof(planes[0]);
 		alloc_ok = (eff->energies != NULL && eff->efficiencies != NULL);
-		for (size_t k = 0; k < sizeof(planes)/sizeof(planes[0]); k++) {
-			*planes[k] = pc_plane_calloc(nalloc, sizeof(double), zeroed);
-			alloc_ok = alloc_ok && (*planes[k] != NULL);
+		if (nalloc*sizeof(double) >= 2*PC_HUGE_PAGE) {
+			/* big result: one slab, every plane at a multiple of 2 MB */
+			const size_t stride = (nalloc*sizeof(double) + PC_HUGE_PAGE - 1) & ~(PC_HUGE_PAGE - 1);
+			const size_t wbytes = nalloc*ne*sizeof(double);
+			char *slab = pc_plane_calloc(nplanes*stride + wbytes, 1, zeroed);
+			alloc_ok = alloc_ok && slab != NULL;
+			if (slab != NULL) {
+				im->slab = slab; im->slab_stride = stride;
+				for (size_t k = 0; k < nplanes; k++) {
+					if (planes[k] != NULL) *planes[k] = (double *)(slab + k*stride);
+					else im->pc_exit_nrefl = (int64_t *)(slab + k*stride);
+				}
+				im->exit_coord_weights = (double *)(slab + nplanes*stride);
+			}
+		} else {
+			for (size_t k = 0; k < nplanes; k++) {
+				if (planes[k] != NULL) { *planes[k] = pc_plane_calloc(nalloc, sizeof(double), zeroed); alloc_ok = alloc_ok && (*planes[k] != NULL); }
+				else { im->pc_exit_nrefl = pc_plane_calloc(nalloc, sizeof(int64_t), zeroed); alloc_ok = alloc_ok && im->pc_exit_nrefl != NULL; }
+			}
+			im->exit_coord_weights = pc_plane_calloc(nalloc*ne, sizeof(double), zeroed);
+			alloc_ok = alloc_ok && im->exit_coord_weights != NULL;
 		}
-		im->pc_exit_nrefl = pc_plane_calloc(nalloc, sizeof(int64_t), zeroed);
-		im->exit_coord_weights = pc_plane_calloc(nalloc*ne, sizeof(double), zeroed);
-		alloc_ok = alloc_ok && im->pc_exit_nrefl != NULL && im->exit_coord_weights != NULL;
 	}
 	if (!alloc_ok) {
 		polycap_set_error(error, POLYCAP_ERROR_MEMORY, "%s: could not allocate memory for efficiencies -> %s", caller, strerror(errno));
@@ -274,13 +300,20 @@ void pc_transeff_prefault(polycap_transmission_efficiencies *eff, size_t np)
 	pc_transeff_plane_pointers(eff, &d);
 	struct pc_touch_job jobs[18];
 	int nj = 0;
+	if (eff->images->slab != NULL) {
+		if (pc_plane_pooled_ready(eff->images->slab))
+			return;          /* from the pool: faulted in and pinned already */
+		jobs[0].base = eff->images->slab;
+		jobs[0].bytes = 17*eff->images->slab_stride + np*eff->n_energies*sizeof(double);
+		nj = 1;
+	}
 	void *planes[] = { d.src_start_coords[0], d.src_start_coords[1], d.pc_start_coords[0], d.pc_start_coords[1],
 		d.pc_start_dir[0], d.pc_start_dir[1], d.pc_start_elecv[0], d.pc_start_elecv[1],
 		d.pc_exit_coords[0], d.pc_exit_coords[1], d.pc_exit_coords[2], d.pc_exit_dir[0], d.pc_exit_dir[1],
 		d.pc_exit_elecv[0], d.pc_exit_elecv[1], d.pc_exit_nrefl, d.pc_exit_dtravel };
-	for (size_t k = 0; k < sizeof(planes)/sizeof(planes[0]); k++)
+	for (size_t k = 0; k < sizeof(planes)/sizeof(planes[0]) && eff->images->slab == NULL; k++)
 		if (planes[k] != NULL && !pc_plane_pooled_ready(planes[k])) { jobs[nj].base = planes[k]; jobs[nj].bytes = np*sizeof(double); nj++; }
-	if (d.exit_coord_weights != NULL && !pc_plane_pooled_ready(d.exit_coord_weights)) { jobs[nj].base = (char *)d.exit_coord_weights; jobs[nj].bytes = np*eff->n_energies*sizeof(double); nj++; }
+	if (eff->images->slab == NULL && d.exit_coord_weights != NULL && !pc_plane_pooled_ready(d.exit_coord_weights)) { jobs[nj].base = (char *)d.exit_coord_weights; jobs[nj].bytes = np*eff->n_energies*sizeof(double); nj++; }
 	if (nj == 0)
 		return;          /* every plane comes from the pool: faulted in and pinned already */
 	long cores = sysconf(_SC_NPROCESSORS_ONLN);
@@ -307,14 +340,8 @@ void pc_transeff_planes_pinned(polycap_transmission_efficiencies *eff)
 {
 	if (eff == NULL || eff->images == NULL)
 		return;
-	pc_hip_images d;
-	pc_transeff_plane_pointers(eff, &d);
-	void *planes[] = { d.src_start_coords[0], d.src_start_coords[1], d.pc_start_coords[0], d.pc_start_coords[1],
-		d.pc_start_dir[0], d.pc_start_dir[1], d.pc_start_elecv[0], d.pc_start_elecv[1],
-		d.pc_exit_coords[0], d.pc_exit_coords[1], d.pc_exit_coords[2], d.pc_exit_dir[0], d.pc_exit_dir[1],
-		d.pc_exit_elecv[0], d.pc_exit_elecv[1], d.pc_exit_nrefl, d.pc_exit_dtravel, d.exit_coord_weights };
-	for (size_t k = 0; k < sizeof(planes)/sizeof(planes[0]); k++)
-		pc_plane_set_pinned(planes[k], 1);
+	if (eff->images->slab != NULL)
+		pc_plane_set_pinned(eff->images->slab, 1);
 }
 
 /* totals -> open area, counts and efficiencies (reference: src/polycap-source.c:1061-1076) */

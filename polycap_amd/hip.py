@@ -149,7 +149,7 @@ class TraceContext:
                     i_exit=int(cnt[0]), not_entered=int(cnt[1]), not_transmitted=int(cnt[2]), sum_irefl=int(cnt[3]),
                     failed_slots=int(cnt[4]), launches=int(cnt[5]), i_start=int(cnt[0] + cnt[1] + cnt[2]))
 
-    KERNELS = {0: "pc_trace_kernel", 1: "pc_trace_pool_kernel", 2: "pc_trace_producer_kernel"}
+    KERNELS = {0: "pc_trace_kernel", 1: "pc_trace_pool_kernel", 2: "pc_trace_producer_kernel", 3: "pc_trace_wave_kernel"}
 
     def last_kernel(self):
         """Name of the kernel that traced the last source run (None before the first)."""
@@ -247,6 +247,11 @@ class TraceGroup:
         st = self._L.pc_hip_group_set_option(self._h, name.encode(), int(value))
         if st != _cabi.PC_HIP_OK:
             raise HipError("pc_hip_group_set_option", st)
+
+    def last_kernels(self):
+        """Names of the kernels that traced the members' shares of the last run."""
+        n = int(self._L.pc_hip_group_size(self._h))
+        return [TraceContext.KERNELS.get(int(self._L.pc_hip_group_last_kernel(self._h, k))) for k in range(n)]
 
     def transmission(self, seed, n_slots, max_attempts=1 << 20, keep_images=False, reduce=-1):
         """reduce: -1 automatic (RCCL when the devices are distinct and librccl loads), 0 host sum, 1 RCCL or fail"""

@@ -17,13 +17,13 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(root, "profiles", sys.argv[2] if len(sys.argv) > 2 else "r02")
 os.makedirs(out_dir, exist_ok=True)
-ks = glob.glob(os.path.join(root, "gpurun_out", "prof_%s_kt" % tag, "*", "*_kernel_stats.csv"))
+ks = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_%s_kt" % tag, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 if ks:
-    shutil.copy(ks[0], os.path.join(out_dir, "%s_kernel_stats.csv" % tag))
+    shutil.copy(ks[-1], os.path.join(out_dir, "%s_kernel_stats.csv" % tag))
 summary = {}
 meta = {}
 for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_%s_pmc*" % tag))):
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:     # the newest pass only
         rows = [r for r in csv.DictReader(open(f)) if "pc_trace" in r["Kernel_Name"]]
         # the trace kernel of the timed steps: the one with the most dispatches (a context's first big run is preceded by a
         # small probe launch of the default kernel, which is not what is profiled)

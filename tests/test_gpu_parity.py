@@ -126,7 +126,8 @@ def test_explicit_photons_vs_oracle(pa, oracle):
         # measured on the oracle itself: a 1-ulp input change flips rc or i_refl for 13-15 % of photons; the kernel
         # differs from the oracle by rounding only, so it must stay well below that
         flips = ((o["rc"] != g["rc"]) | (o["i_refl"] != g["i_refl"])).mean()
-        assert flips < 0.06, flips                      # observed 3.9 % (profiles/r02/parity_1e8.json)
+        # observed: xos1 3.9 % (profiles/r02/parity_1e8.json), the ellipsoidal test optic 6.8 % (its photons reflect more often)
+        assert flips < (0.06 if which == "xos1" else 0.08), (which, flips)
         # short trajectories (<= 3 reflections): amplification is still small
         short = (o["rc"] == g["rc"]) & (o["i_refl"] == g["i_refl"]) & (o["i_refl"] <= 3) & np.isin(o["rc"], (0, 1))
         assert short.sum() >= 5
@@ -663,6 +664,35 @@ def test_device_group_is_bit_identical_to_one_device(pa, oracle):
         h7 = grp.transmission(3, 50_000)
     assert np.array_equal(r7["sumw_fixed"], one7["sumw_fixed"]) and np.array_equal(h7["sumw_fixed"], one7["sumw_fixed"])
     assert np.array_equal(r7["counters"][:4], one7["counters"][:4]) and np.array_equal(h7["counters"][:4], one7["counters"][:4])
+
+
+def test_device_group_members_share_one_probe_and_enqueue_concurrently(pa):
+    """BASELINE C2 over a device list as the 8-GPU node would run it (here [0, 0, 0, 0] on the one GPU: 4 x 1.25e6 slots, each
+    below the size from which a context probes by itself): one probe decides the kernel for every member -- the launching-wave
+    kernel on xos1 --, the members are enqueued from host threads without a blocking call between them, and the whole run costs
+    about what one context needs for the same slots (the members' kernels follow each other on the one GPU; on distinct GPUs
+    they run side by side)."""
+    import os
+    import time
+    from tests.conftest import EXAMPLE
+    prob = pa.problem_from_inp(os.path.join(EXAMPLE, "xos1.inp"), energies=[10.0])
+    n = 5_000_000
+    with pa.TraceContext(prob) as ctx:
+        ctx.transmission(1, 0, n)                      # warm-up: probe + kernel choice
+        t0 = time.perf_counter()
+        one = ctx.transmission(7, 0, n)
+        t_one = time.perf_counter() - t0
+        assert ctx.last_kernel() == "pc_trace_producer_kernel"
+    with pa.TraceGroup(prob, [0, 0, 0, 0]) as grp:
+        grp.transmission(1, n)                         # warm-up: the group's one probe
+        assert grp.last_kernels() == ["pc_trace_producer_kernel"] * 4
+        t0 = time.perf_counter()
+        g = grp.transmission(7, n)
+        t_grp = time.perf_counter() - t0
+        assert grp.last_kernels() == ["pc_trace_producer_kernel"] * 4
+    assert np.array_equal(g["counters"][:4], one["counters"][:4]) and np.array_equal(g["sumw_fixed"], one["sumw_fixed"])
+    print("one context %.2f ms, four members %.2f ms" % (t_one * 1e3, t_grp * 1e3))
+    assert t_grp <= 1.15 * t_one + 1.5e-3, (t_grp, t_one)
 
 
 def test_c_api_multi_device_and_histogram_only(pa, monkeypatch):
