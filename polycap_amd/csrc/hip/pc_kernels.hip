@@ -44,9 +44,16 @@
 #endif
 #define PC_KE 5                /* energies per lane whose weights are in flight together in a cooperative sweep */
 #ifndef PC_KB
-#define PC_KB 5                /* reflections of a photon that wait for one sweep of its weights (many-energy kernel): 120 B of LDS per lane.
-                                * xos1 291 energies 1e6 slots / ellip_l9 291 sig 5 A 5e5 / xos1 100 energies, kernel ms: 4: 42.3 / 28.7 / 18.3,
-                                * 5: 38.9 / 27.9 / 16.8 (scripts/ab_ne3.sh; 6 does not fit next to the tables) */
+#define PC_KB 4                /* reflections of a photon that wait for one sweep of its weights (batched many-energy kernel): 96 B of LDS
+                                * per lane.  With 8 waves per CU (512 lanes), xos1 291 energies 1e6 slots / ellip_l9 291 sig 5 A 5e5 / xos1 100
+                                * energies, kernel ms: 4: 42.3 / 28.7 / 18.3, 5: 38.9 / 27.9 / 16.8 (scripts/ab_ne3.sh); with 12 waves
+                                * (PC_BLOCK_BATCH 768) 4 is what fits next to the tables */
+#endif
+#ifndef PC_BLOCK_BATCH
+#define PC_BLOCK_BATCH 768     /* workgroup of the batched many-energy kernel (pc_trace_kernel<0, MODE, 1024, true>): 12 waves per CU, 3 per SIMD */
+#endif
+#ifndef PC_WAVES_BATCH
+#define PC_WAVES_BATCH 3       /* ... and the waves per SIMD its registers must leave room for (168 VGPRs) */
 #endif
 #ifndef PC_SWEEP_IL
 #define PC_SWEEP_IL 1          /* (photon, energy) items a lane has in flight together in the flat sweep of the many-energy kernel */
@@ -251,25 +258,34 @@ __device__ __forceinline__ int pc_reflect_energy_sweep(const pc_energy_const &ec
  * source; PC_MODE_SRC_CIRCULAR / _GENERIC: photons are sampled from the source (circular / elliptical). */
 enum { PC_MODE_SRC_CIRCULAR = 0, PC_MODE_SRC_GENERIC = 1, PC_MODE_EXPLICIT = 2 };
 
-template <int NE, int MODE, int PITCH>
-__global__ void __launch_bounds__(PC_BLOCK, NE == 0 ? PC_MIN_WAVES_NE0 : PC_MIN_WAVES)
+/* BATCH (NE == 0, source modes, profiles of up to 1024 points): the kernel of runs with more than 32 energies whose
+ * reflections wait in LDS for the flat sweep (pc_kargs::lds_pend).  An instantiation of its own, without the immediate
+ * sweeps: 171 instead of 237 VGPRs, so that three waves per SIMD fit (its sweep is bound by VALU issue and its trace phases
+ * by latency: more waves help both), and with the two tables only the EVENT phase reads (hexd, idz) left in global memory
+ * to make room in LDS for the reflections of 768 lanes. */
+template <int NE, int MODE, int PITCH, bool BATCH = false>
+__global__ void __launch_bounds__(BATCH ? PC_BLOCK_BATCH : PC_BLOCK, BATCH ? PC_WAVES_BATCH : (NE == 0 ? PC_MIN_WAVES_NE0 : PC_MIN_WAVES))
 pc_trace_kernel(pc_kargs a)
 {
 	constexpr bool EXPLICIT = (MODE == PC_MODE_EXPLICIT);
+	static_assert(!BATCH || (NE == 0 && MODE != PC_MODE_EXPLICIT), "the batched kernel serves many-energy source runs");
 	/* static LDS with a compile-time pitch: table reads become ds_read with immediate offsets */
-	__shared__ double lds[6*PITCH];
+	__shared__ double lds[(BATCH ? 4 : 6)*PITCH];
 	__shared__ pc_marg4 ldsg[PITCH];
 	/* NE == 0: per-workgroup exact weight sums, (lo, hi) per energy, when they fit (a.lds_acc); else global atomics */
 	extern __shared__ unsigned long long l_acc[];
 	const int npts = a.pm.nmax + 1;
-	double *l_z = lds, *l_cap = lds + PITCH, *l_zh = lds + 2*PITCH, *l_cap2 = lds + 3*PITCH, *l_hexd = lds + 4*PITCH, *l_idz = lds + 5*PITCH;
+	double *l_z = lds, *l_cap = lds + PITCH, *l_zh = lds + 2*PITCH, *l_cap2 = lds + 3*PITCH;
+	double *l_hexd = BATCH ? nullptr : lds + 4*PITCH, *l_idz = BATCH ? nullptr : lds + 5*PITCH;
 	for (int k = threadIdx.x; k < npts; k += blockDim.x) {
 		l_z[k] = a.g_z[k];
 		l_cap[k] = a.g_cap[k];
 		l_zh[k] = a.g_zh[k];
 		l_cap2[k] = a.g_cap2[k];
-		l_hexd[k] = a.g_hexd[k];
-		l_idz[k] = a.g_idz[k];
+		if (!BATCH) {
+			l_hexd[k] = a.g_hexd[k];
+			l_idz[k] = a.g_idz[k];
+		}
 		ldsg[k] = a.g_mg[k];
 	}
 	if (NE != 1 && a.lds_acc)
@@ -282,7 +298,8 @@ pc_trace_kernel(pc_kargs a)
 	}
 	__syncthreads();
 	pc_tables T;
-	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.hexd = l_hexd; T.idz = l_idz; T.ext = a.g_ext;
+	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.ext = a.g_ext;
+	if (BATCH) { T.hexd = a.g_hexd; T.idz = a.g_idz; } else { T.hexd = l_hexd; T.idz = l_idz; }
 	T.mg = ldsg;
 	const long long fs = a.img_fs, ss = a.img_ss, ws = a.img_ws;      /* strides of the image store: records or planes (pc_kargs) */
 	const pc_params &Pm = a.pm;
@@ -324,7 +341,7 @@ pc_trace_kernel(pc_kargs a)
 	 * reflection that absorbs the photon (no weight >= 1e-4 left) or fails (return -1): the photon then ends there, as in
 	 * the reference, and what it did afterwards is dropped (a photon that ends with rc -1/0/1 is swept before it is
 	 * finalised, so nothing speculative is ever counted). */
-	double *const l_pend = (NE == 0 && a.lds_pend) ? (double *)(l_acc + 2*a.pm.n_energies) + 6*a.pm.n_energies : nullptr;
+	double *const l_pend = BATCH ? (double *)(l_acc + 2*a.pm.n_energies) + 6*a.pm.n_energies : nullptr;
 	/* The sweep is FLAT over (photon, energy) pairs: the photons of the wave whose reflections are due form one list of
 	 * nP x n_energies items, lane l takes items l, l + 64, ...  (291 energies fill 4.55 passes of one photon -- 9 % idle lanes --
 	 * but 12 photons, the usual number after an EVENT phase, fill 54.6 of 55).  Per wave, in LDS behind the waiting reflections:
@@ -462,7 +479,7 @@ pc_trace_kernel(pc_kargs a)
 	};
 
 	for (;;) {
-		if (NE == 0 && a.lds_pend) {
+		if (BATCH) {
 			/* weights are swept when a photon's PC_KB places are full, and before a finished photon is finalised (the one place
 			 * the sweep is instantiated: every photon that is due goes into the same flat list) */
 			const unsigned long long mF = __ballot(npend == PC_KB || (state == LS_DONE && npend > 0));
@@ -622,7 +639,7 @@ pc_trace_kernel(pc_kargs a)
 						if (lane == p) res = anybad ? -1 : (anykeep ? 1 : 0);
 					}
 				};
-				if (NE == 0 && a.lds_pend) {
+				if (BATCH) {
 					/* the reflection waits (see flush above); the photon goes on as a survivor.  A geometry the reference rejects
 					 * (pend == 2) ends the photon with rc -1 unless a waiting reflection ends it first: both are settled
 					 * by the sweep that precedes the finalisation of every finished photon */
@@ -635,7 +652,7 @@ pc_trace_kernel(pc_kargs a)
 				} else if (NE == 0 && a.lds_ec) sweep((const double *)(l_acc + 2*a.pm.n_energies));
 				else sweep(a.ec_soa);
 				if (pend) {
-					if (pend == 1) { if (!(NE == 0 && a.lds_pend)) ph.wset = 1; ph.ex = fabs(ph.ex); ph.ey = fabs(ph.ey); ph.ez = fabs(ph.ez); }
+					if (pend == 1) { if (!BATCH) ph.wset = 1; ph.ex = fabs(ph.ex); ph.ey = fabs(ph.ey); ph.ez = fabs(ph.ez); }
 					state = pc_event_post(Pm, ph, h, res);
 				}
 			}
@@ -1024,6 +1041,9 @@ static int pc_fail(int code, const std::string &msg)
 struct pc_hip_ctx {
 	int device = 0;
 	int n_cu = 256;
+	int cu_share = 1;              /* option "cu_share": the context's launches fill n_cu / cu_share compute units.  Tried for device groups that list
+	                                * a device m times (m kernels side by side on a quarter of the CUs each): the kernels of one process's streams
+	                                * did not overlap (21.7 ms against 15.1 ms one after the other, xos1 5e6 slots, 4 members), so groups leave it at 1 */
 	hipStream_t stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	pc_host_tables host;
@@ -1144,6 +1164,12 @@ struct pc_hip_ctx {
 	long long leak_n_ext = 0, leak_n_int = 0;
 };
 
+static int pc_cus(const pc_hip_ctx *ctx)
+{
+	const int n = ctx->n_cu / (ctx->cu_share > 0 ? ctx->cu_share : 1);
+	return n > 0 ? n : 1;
+}
+
 static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
 {
 	const size_t npts = (size_t)ctx->host.pm.nmax + 1;
@@ -1166,15 +1192,28 @@ static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
 	a.sumw = (unsigned long long *)(ctx->d_totals + 1);
 }
 
+/* dynamic LDS of the any-n_energies kernel: exact sums, per-energy constants and -- batched kernel -- the waiting reflections
+ * and the per-wave tables of the flat sweep */
+static size_t pc_ne0_dyn_lds(size_t ne, int lds_acc, int lds_ec, int lds_pend, int block)
+{
+	return (lds_acc ? 2*ne*sizeof(unsigned long long) : 0) + (lds_ec ? 6*ne*sizeof(double) : 0)
+	     + (lds_pend ? (size_t)block*3*PC_KB*sizeof(double) + (size_t)(block/PC_WAVE)*3*PC_WAVE*sizeof(unsigned int) : 0);
+}
+
 template <int NE, int MODE>
 static int pc_launch_one(pc_hip_ctx *ctx, const pc_kargs &a, int grid)
 {
 	/* table pitch: 1024 entries (48 KB of LDS) covers the reference's generated profiles (nmax = 999) and its example decks */
-	const size_t dyn = ((NE != 1 && a.lds_acc) ? 2*(size_t)ctx->host.pm.n_energies*sizeof(unsigned long long) : 0)
-	                 + ((NE == 0 && a.lds_ec) ? 6*(size_t)ctx->host.pm.n_energies*sizeof(double) : 0)
-	                 + ((NE == 0 && a.lds_pend) ? (size_t)(a.total_threads / grid)*3*PC_KB*sizeof(double)
-	                                              + (size_t)(a.total_threads / grid / PC_WAVE)*3*PC_WAVE*sizeof(unsigned int) : 0);
 	const int block = (int)(a.total_threads / grid);
+	const size_t dyn = (NE == 0) ? pc_ne0_dyn_lds((size_t)ctx->host.pm.n_energies, a.lds_acc, a.lds_ec, a.lds_pend, block)
+	                             : ((NE != 1 && a.lds_acc) ? 2*(size_t)ctx->host.pm.n_energies*sizeof(unsigned long long) : 0);
+	if constexpr (NE == 0 && MODE != PC_MODE_EXPLICIT) {
+		if (a.lds_pend) {
+			hipLaunchKernelGGL((pc_trace_kernel<0, MODE, 1024, true>), dim3(grid), dim3(block), dyn, ctx->stream, a);
+			PC_HIP_CHECK(hipGetLastError());
+			return PC_HIP_OK;
+		}
+	}
 	if (ctx->host.pm.nmax + 1 <= 1024)
 		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, 1024>), dim3(grid), dim3(block), dyn, ctx->stream, a);
 	else if (NE <= 1)   /* long profiles: only the NE = 1 and the any-n_energies kernels are built for the 2048 pitch */
@@ -1218,7 +1257,8 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		if (c.valid == 0.) all_valid = false;
 		if (c.rough_c != 0.) a.sweep_rough = 1;
 	}
-	a.lds_pend = (a.lds_ec && ne > 32 && ctx->batch_reflections && all_valid && MODE != PC_MODE_EXPLICIT) ? 1 : 0;   /* source runs only: an explicit
+	a.lds_pend = (a.lds_ec && ne > 32 && ctx->batch_reflections && all_valid && MODE != PC_MODE_EXPLICIT
+	              && 4*1024*sizeof(double) + 1024*sizeof(pc_marg4) + pc_ne0_dyn_lds((size_t)ne, 1, 1, 1, PC_BLOCK_BATCH) <= 163840) ? 1 : 0;   /* source runs only: an explicit
 	                                       * photon reports its state at the absorbing reflection, which the speculation overwrites */
 	if constexpr (MODE != PC_MODE_EXPLICIT) {
 		if (ctx->wave_per_photon && ne == 1 && !a.keep_images && ctx->host.pm.nmax + 1 <= 1024) {
@@ -1241,7 +1281,7 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 			const long long per_block = (long long)PC3_CONSUMERS*PC_WAVE;
 			long long want = (n_items + per_block - 1) / per_block;
 			const long long per_cu = (PC3_BLOCK > 512) ? 1 : 2;
-			int grid = (int)(want < per_cu*ctx->n_cu ? want : per_cu*ctx->n_cu);
+			int grid = (int)(want < per_cu*pc_cus(ctx) ? want : per_cu*pc_cus(ctx));
 			if (grid < 1) grid = 1;
 			a.total_threads = (long long)grid * PC3_BLOCK;
 			a.event_threshold = ctx->event_threshold;
@@ -1259,7 +1299,7 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		/* one 1024-thread workgroup per CU; a wave holds 64 + PQ_P photons */
 		const long long per_block = (long long)PQ_WAVES*(PC_WAVE + PQ_P);
 		long long want = (n_items + per_block - 1) / per_block;
-		int grid = (int)(want < ctx->n_cu ? want : ctx->n_cu);
+		int grid = (int)(want < pc_cus(ctx) ? want : pc_cus(ctx));
 		if (grid < 1) grid = 1;
 		a.total_threads = (long long)grid * PQ_BLOCK;
 		a.event_threshold = ctx->pool_march_min;
@@ -1273,8 +1313,8 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		if (ctx->rec_ev1) PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
 		return PC_HIP_OK;
 	}
-	long long max_blocks = (long long)ctx->n_cu * ((kne == 0) ? 1 : ctx->blocks_per_cu);
-	const int block = ctx->block_size;
+	long long max_blocks = (long long)pc_cus(ctx) * ((kne == 0) ? 1 : ctx->blocks_per_cu);
+	const int block = (kne == 0 && a.lds_pend) ? PC_BLOCK_BATCH : ctx->block_size;      /* the batched many-energy kernel: 12 waves per CU */
 	long long want_blocks = (n_items + block - 1) / block;
 	int grid = (int)(want_blocks < max_blocks ? want_blocks : max_blocks);
 	if (grid < 1) grid = 1;
@@ -1436,6 +1476,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "fetch_threads") { if (value < 0 || value > 256) return pc_fail(PC_HIP_ERR_INVALID, "fetch_threads must be in [0,256]"); ctx->fetch_threads = (int)value; }
 	else if (n == "pool") ctx->pool = value ? 1 : 0;
 	else if (n == "wave_per_photon") ctx->wave_per_photon = value ? 1 : 0;
+	else if (n == "cu_share") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "cu_share must be in [1,64]"); ctx->cu_share = (int)value; }
 	else if (n == "producer") { if (value < -1 || value > 1) return pc_fail(PC_HIP_ERR_INVALID, "producer must be -1 (automatic), 0 or 1"); ctx->producer = (int)value; }
 	else if (n == "producer_new_min") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "producer_new_min must be in [1,64]"); ctx->producer_new_min = (int)value; }
 	else if (n == "producer_new_first") { if (value < 1 || value > 65) return pc_fail(PC_HIP_ERR_INVALID, "producer_new_first must be in [1,65]"); ctx->producer_new_first = (int)value; }

@@ -255,7 +255,10 @@ class TraceGroup:
 
     def transmission(self, seed, n_slots, max_attempts=1 << 20, keep_images=False, reduce=-1):
         """reduce: -1 automatic (RCCL when the devices are distinct and librccl loads), 0 host sum, 1 RCCL or fail"""
+        import time
+        t0 = time.perf_counter()
         st = self._L.pc_hip_group_run(self._h, int(seed), int(n_slots), int(max_attempts), int(bool(keep_images)))
+        self.enqueue_s = time.perf_counter() - t0          # pc_hip_group_run only enqueues: the members trace asynchronously
         if st != _cabi.PC_HIP_OK:
             raise HipError("pc_hip_group_run", st)
         ne = self.problem.n_energies
