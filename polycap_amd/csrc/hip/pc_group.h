@@ -222,7 +222,6 @@ int pc_hip_group_images(pc_hip_group *g, const pc_hip_images *dst)
 	 * a member that pinned and unpinned its own range would unpin a neighbour's first page under its running copy (the members
 	 * find their ranges pinned already and leave them alone). */
 	std::vector<void *> pinned;
-	bool all_pinned = N > 1;
 	if (N > 1) {
 		void *planes[PC_N_FIELDS + 1] = {
 			dst->src_start_coords[0], dst->src_start_coords[1], dst->pc_start_coords[0], dst->pc_start_coords[1],
@@ -231,23 +230,13 @@ int pc_hip_group_images(pc_hip_group *g, const pc_hip_images *dst)
 			dst->pc_exit_dir[0], dst->pc_exit_dir[1], dst->pc_exit_elecv[0], dst->pc_exit_elecv[1],
 			dst->pc_exit_nrefl, dst->pc_exit_dtravel, dst->exit_coord_weights };
 		(void)hipSetDevice(g->devices[0]);
-		for (int f = 0; f <= PC_N_FIELDS; f++) {
-			if (!planes[f]) continue;
-			const size_t bytes = (size_t)g->run_slots*sizeof(double)*(f < PC_N_FIELDS ? 1 : ne);
-			const hipError_t re = pc_host_is_pinned(planes[f]) ? hipErrorHostMemoryAlreadyRegistered : hipHostRegister(planes[f], bytes, hipHostRegisterPortable);
-			if (re == hipSuccess) pinned.push_back(planes[f]);
-			else {
-				(void)hipGetLastError();
-				if (re != hipErrorHostMemoryAlreadyRegistered) all_pinned = false;
-			}
-		}
-		if (!all_pinned) {
-			/* some plane could not be pinned: nothing is, and the members copy through their own (slower) paths */
-			for (void *p : pinned) (void)hipHostUnregister(p);
-			pinned.clear();
-		}
+		std::vector<std::pair<char *, size_t>> ranges;
+		for (int f = 0; f <= PC_N_FIELDS; f++)
+			if (planes[f]) ranges.emplace_back((char *)planes[f], (size_t)g->run_slots*sizeof(double)*(f < PC_N_FIELDS ? 1 : ne));
+		/* pinned or not, the members pin nothing themselves: they would pin neighbouring pieces of the same pages */
+		(void)pc_pin_ranges(ranges, hipHostRegisterPortable, pinned);
+		for (pc_hip_ctx *c : g->ctx) c->dst_prepinned = 1;
 	}
-	for (pc_hip_ctx *c : g->ctx) c->dst_prepinned = all_pinned ? 1 : 0;
 	std::vector<std::thread> th;
 	for (size_t k = 1; k < N; k++) th.emplace_back(fetch, k);
 	fetch(0);

@@ -1996,6 +1996,39 @@ static bool pc_host_is_pinned(void *p)
 	return false;
 }
 
+/* Pins the host ranges (address, bytes) for the copy engine: rounded out to pages, overlapping or touching ranges merged (small
+ * planes from malloc share pages with their neighbours, and a page cannot be registered twice), ranges that are pinned already
+ * left alone.  All or nothing: when one range cannot be pinned the ones pinned here are released again and false is returned
+ * -- a destination that is pinned only in part is not something to hand to hipMemcpyAsync.  `pinned` receives what to
+ * hipHostUnregister afterwards. */
+static bool pc_pin_ranges(std::vector<std::pair<char *, size_t>> ranges, unsigned int flags, std::vector<void *> &pinned)
+{
+	const uintptr_t page = 4096;
+	std::vector<std::pair<uintptr_t, uintptr_t>> r;
+	for (auto &x : ranges) {
+		if (!x.first || !x.second) continue;
+		const uintptr_t lo = (uintptr_t)x.first & ~(page - 1), hi = ((uintptr_t)x.first + x.second + page - 1) & ~(page - 1);
+		r.emplace_back(lo, hi);
+	}
+	std::sort(r.begin(), r.end());
+	std::vector<std::pair<uintptr_t, uintptr_t>> m;
+	for (auto &x : r) {
+		if (!m.empty() && x.first <= m.back().second) m.back().second = std::max(m.back().second, x.second);
+		else m.push_back(x);
+	}
+	const size_t before = pinned.size();
+	for (auto &x : m) {
+		if (pc_host_is_pinned((void *)x.first) && pc_host_is_pinned((void *)(x.second - 1))) continue;
+		if (hipHostRegister((void *)x.first, (size_t)(x.second - x.first), flags) != hipSuccess) {
+			(void)hipGetLastError();
+			while (pinned.size() > before) { (void)hipHostUnregister(pinned.back()); pinned.pop_back(); }
+			return false;
+		}
+		pinned.push_back((void *)x.first);
+	}
+	return true;
+}
+
 static hipError_t pc_fetch_stream_ensure(pc_hip_ctx *ctx)
 {
 	if (ctx->fetch_stream) return hipSuccess;
@@ -2054,19 +2087,17 @@ static int pc_fetch_planes_direct(pc_hip_ctx *ctx, int64_t first, int64_t count,
 			if (rw == hipSuccess) pinned.push_back(weights); else (void)hipGetLastError();
 		}
 	}
-	for (int k = 0; k <= PC_N_FIELDS && !slab_stride && pin_here; k++) {
-		void *p = (k < PC_N_FIELDS) ? planes[k] : (void *)weights;
-		if (!p) continue;
-		const size_t bytes = (size_t)count*sizeof(double)*(k < PC_N_FIELDS ? 1 : ne);
-		const hipError_t re = pc_host_is_pinned(p) ? hipErrorHostMemoryAlreadyRegistered : hipHostRegister(p, bytes, hipHostRegisterDefault);
-		if (re == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); continue; }      /* pinned by an earlier call (option keep_pinned) */
-		if (re != hipSuccess) {
-			(void)hipGetLastError();
-			if (ctx->run_planes) continue;        /* planes are all there is: this destination is copied unpinned (slower, still right) */
-			unpin();
-			return 1;
+	if (!slab_stride && pin_here) {
+		std::vector<std::pair<char *, size_t>> ranges;
+		for (int k = 0; k <= PC_N_FIELDS; k++) {
+			void *p = (k < PC_N_FIELDS) ? planes[k] : (void *)weights;
+			if (p) ranges.emplace_back((char *)p, (size_t)count*sizeof(double)*(k < PC_N_FIELDS ? 1 : ne));
 		}
-		pinned.push_back(p);
+		if (!pc_pin_ranges(ranges, hipHostRegisterDefault, pinned) && !ctx->run_planes) {
+			unpin();
+			return 1;         /* a record run: the staging pipeline copies without pinning the destination */
+		}
+		/* (a plane run whose destination cannot be pinned is copied unpinned: slower, still right) */
 	}
 	const double t_pinned = now_ms();
 	int status = PC_HIP_OK;
@@ -2103,7 +2134,7 @@ static int pc_fetch_planes_direct(pc_hip_ctx *ctx, int64_t first, int64_t count,
 				if ((++spins & 63ul) == 0ul) {
 					const hipError_t q = hipEventQuery(ctx->ev1);
 					if (q == hipSuccess) kernel_done = true;
-					else if (q != hipErrorNotReady) { status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_transmission_images: ") + hipGetErrorString(q)); break; }
+					else if (q != hipErrorNotReady) { status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_transmission_images (kernel event query): ") + hipGetErrorString(q)); break; }
 					(void)hipGetLastError();
 				}
 				std::this_thread::yield();
@@ -2116,7 +2147,7 @@ static int pc_fetch_planes_direct(pc_hip_ctx *ctx, int64_t first, int64_t count,
 			if (group >= depth) {
 				for (int k = 0; k < n_streams && status == PC_HIP_OK; k++) {
 					const hipError_t we = hipEventSynchronize(ctx->ev_group[k][(group - depth) & 3]);
-					if (we != hipSuccess) status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_transmission_images: ") + hipGetErrorString(we));
+					if (we != hipSuccess) status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_transmission_images (wait for a group of copies): ") + hipGetErrorString(we));
 				}
 				if (status != PC_HIP_OK) break;
 			}
@@ -2142,9 +2173,11 @@ static int pc_fetch_planes_direct(pc_hip_ctx *ctx, int64_t first, int64_t count,
 					                     (size_t)(hi - lo)*ne*sizeof(double), hipMemcpyDeviceToHost, streams[f & 1]);
 				}
 			}
-			for (int k = 0; k < n_streams && err == hipSuccess; k++)
+			if (err != hipSuccess) status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_transmission_images (copy of a group of blocks): ") + hipGetErrorString(err));
+			for (int k = 0; k < n_streams && err == hipSuccess; k++) {
 				err = hipEventRecord(ctx->ev_group[k][group & 3], streams[k]);
-			if (err != hipSuccess) status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_transmission_images: ") + hipGetErrorString(err));
+				if (err != hipSuccess) status = pc_fail(PC_HIP_ERR_RUNTIME, std::string("pc_hip_transmission_images (event after a group of copies): ") + hipGetErrorString(err));
+			}
 			b = e;
 			group++;
 		}
