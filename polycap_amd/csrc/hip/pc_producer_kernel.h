@@ -423,6 +423,7 @@ pc_trace_producer_kernel(pc_kargs a)
 			} else if (nN > 0) {
 				/* ---------------- NEW: finalise finished photons, pop launched ones */
 				st_new += 1; st_new_l += (unsigned)nN;
+				int moved = 0;                /* photons pushed or popped in this phase */
 				{
 					/* finished photons go to the launching wave (as many as its ring takes; the others wait for the next NEW phase) */
 					const unsigned long long mD = __ballot(state == LS_DONE);
@@ -442,6 +443,7 @@ pc_trace_producer_kernel(pc_kargs a)
 						const int k = __popcll(mD);
 						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 						r_tail += (unsigned)(k < room ? k : room);
+						moved += (k < room ? k : room);
 						if (lane == 0) pc3_store(&ctl.r_tail[c], r_tail);
 					}
 				}
@@ -475,8 +477,16 @@ pc_trace_producer_kernel(pc_kargs a)
 						const int k = __popcll(mQ);
 						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     /* the entries are read before the places are given back */
 						q_head += (unsigned)(k < av ? k : av);
+						moved += (k < av ? k : av);
 						if (lane == 0) pc3_store(&ctl.q_head[c], q_head);
 					}
+				}
+				if (moved == 0 && nM == 0 && nE == 0) {
+					/* nothing could move (the ring of finished photons is full and nothing is there to pop) and nothing else can
+					 * run: wait for the launching wave -- or leave when it has given up (this state used to spin, and
+					 * to spin forever after a give-up) */
+					if (pc3_load(&ctl.failed)) break;
+					__builtin_amdgcn_s_sleep(8);
 				}
 			} else {
 				/* lanes wait for launched photons and nothing else can run */

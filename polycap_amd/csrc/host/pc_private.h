@@ -157,6 +157,7 @@ POLYCAP_EXTERN const char *pc_hdf5_provider(void);
 polycap_transmission_efficiencies *pc_transeff_alloc(polycap_source *source, size_t np, int zeroed, const char *caller, polycap_error **error);
 void pc_transeff_planes_pinned(polycap_transmission_efficiencies *eff);
 POLYCAP_EXTERN void pc_host_pool_clear(void);
+POLYCAP_EXTERN int pc_transmission_efficiencies_slab(const polycap_transmission_efficiencies *efficiencies, void **base, size_t *stride);
 void pc_transeff_prefault(polycap_transmission_efficiencies *eff, size_t np);
 void pc_transeff_plane_pointers(polycap_transmission_efficiencies *eff, pc_hip_images *dst);
 void pc_transeff_finish(polycap_transmission_efficiencies *eff, const double *sum_weights, const int64_t counters[6]);

@@ -181,6 +181,16 @@ static void pc_images_free(struct _polycap_images *images)
 	free(images);
 }
 
+/* tests: where a result's image planes live (1: one slab, *base its address, *stride the bytes between two planes) */
+int pc_transmission_efficiencies_slab(const polycap_transmission_efficiencies *efficiencies, void **base, size_t *stride)
+{
+	if (efficiencies == NULL || efficiencies->images == NULL || efficiencies->images->slab == NULL)
+		return 0;
+	if (base != NULL) *base = efficiencies->images->slab;
+	if (stride != NULL) *stride = efficiencies->images->slab_stride;
+	return 1;
+}
+
 int pc_transmission_efficiencies_synthetic(const polycap_transmission_efficiencies *efficiencies)
 {
 	return efficiencies != NULL ? efficiencies->synthetic_constants : 0;

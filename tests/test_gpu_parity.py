@@ -175,6 +175,12 @@ def test_transmission_driver_vs_oracle(pa, oracle, known):
     assert few.sum() >= 1
     assert np.abs(img[few][:, 8:10] - oi[few][:, 8:10]).max() < 1e-6
     assert rel(g["exit_weights"][few], o["exit_weights"][few]).max() < 1e-6
+    # pc_exit_dtravel: the device adds the path to a hit as (hz - Pz)/dz instead of the reference's sqrt(dx^2+dy^2+dz^2)
+    # (src/polycap-capil.c:1315-1318): the same length of a unit direction up to rounding -- not bit-pinned, so pinned here
+    # against the oracle on the photons that follow it
+    assert rel(img[few][:, 16], oi[few][:, 16]).max() < 1e-12, rel(img[few][:, 16], oi[few][:, 16]).max()
+    same = same_start & (img[:, 15] == oi[:, 15])
+    assert same.sum() > n // 10 and rel(img[same][:, 16], oi[same][:, 16]).max() < 1e-6
 
 
 def test_partition_invariance_and_reproducibility(pa, oracle):

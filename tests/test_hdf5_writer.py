@@ -125,6 +125,48 @@ def test_from_totals_getters(api):
     assert np.array_equal(sd[:, 2], np.sqrt(1. - images[:, 4]**2 - images[:, 5]**2))
 
 
+def test_big_results_live_in_one_slab_and_come_back_from_the_pool(monkeypatch):
+    """pc_transeff.c, round 3: a result of 2^19 photons or more keeps its 17 planes + weights in ONE 2 MB-aligned mapping (the
+    device's planes cross PCIe as one pitched copy per group of blocks, the slab is pinned in one piece) and a freed slab is
+    handed to the next result of the same size; the planes behave like any others (zeroed where the caller gives none)."""
+    import ctypes as C
+    from polycap_amd import capi as api      # the ctypes twin: the test looks at the C object behind the result
+    src = api.Source.new_from_file(DECK)
+    n = 600_000
+    rng = np.random.default_rng(11)
+    images = rng.uniform(-1, 1, size=(n, 17)) * 0.1
+    images[:, 15] = rng.integers(0, 40, size=n)
+    weights = rng.uniform(0, 1, size=(n, NE))
+    counters = np.array([n, 11, 5, int(images[:, 15].sum()), 0, 1], dtype=np.int64)
+    eff = api.TransmissionEfficiencies.from_totals(src, weights.sum(axis=0), counters, images, weights)
+    assert np.array_equal(eff.d_travel, images[:, 16]) and np.array_equal(eff.exit_weights, weights)
+
+    def slab(e):
+        L = api._lib()
+        L.pc_transmission_efficiencies_slab.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.pc_transmission_efficiencies_slab.restype = C.c_int
+        base, stride = C.c_void_p(), C.c_size_t()
+        return (L.pc_transmission_efficiencies_slab(e._h, C.byref(base), C.byref(stride)), base.value, stride.value)
+
+    has, first, stride = slab(eff)
+    assert has == 1 and first % (2 << 20) == 0 and stride % (2 << 20) == 0 and stride >= n * 8
+    del eff
+    # the next result of the same size gets the same memory back (and fresh zeros where no plane is given)
+    eff2 = api.TransmissionEfficiencies.from_totals(src, weights.sum(axis=0), counters, None, None)
+    assert slab(eff2) == (1, first, stride)
+    assert not eff2.d_travel.any() and not eff2.exit_weights.any()
+    del eff2
+    # a small result: planes of their own
+    small = api.TransmissionEfficiencies.from_totals(src, weights[:100].sum(axis=0), np.array([100, 1, 1, 5, 0, 1]), images[:100], weights[:100])
+    assert slab(small)[0] == 0
+    del small
+    monkeypatch.setenv("POLYCAP_HOST_POOL", "0")
+    api._lib().pc_host_pool_clear()
+    eff3 = api.TransmissionEfficiencies.from_totals(src, weights.sum(axis=0), counters, images, weights)
+    assert np.array_equal(eff3.n_refl, images[:, 15].astype(np.int64))
+    del eff3
+
+
 @needs_tools
 def test_file_layout_units_and_values(api, tmp_path):
     src, images, weights, counters, sum_w = _synthetic(api)
