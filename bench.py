@@ -168,8 +168,14 @@ def main():
         avg_ms = float(np.mean(kernel_ms))
         alg_bytes = n_local * (BYTES_PER_EXIT_PHOTON + 8 * ne) if keep_images else 8.0 * (ne + 6)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        sched = ctx.phase_stats()
         kernel = ctx.last_kernel() or "pc_trace_kernel"        # what traced the timed steps (the context picks it, hip.py)
+        # scheduler statistics: the production instantiation of the launching-wave kernel does not count march steps (the ballot
+        # sat in its hot loop); one instrumented launch of the last step's slots outside the timed region fills them in
+        ctx.set_option("march_stats", 1)
+        ctx.run(args.seed + args.steps - 1, slot0, n_local, keep_images=keep_images)
+        ctx.wait()
+        sched = ctx.phase_stats()
+        ctx.set_option("march_stats", 0)
         pmc = pmc_summary(n_local, keep_images, kernel)
         # useful fp64 work of the kernel as executed (after certified skipping), from its own counters: a march lane-step is
         # 6 FMA = 12 flop; a segment visit ~150 flop-equivalents (quadratic, 7 div, 1-2 sqrt, hexagon tests) and a reflection

@@ -1070,6 +1070,8 @@ struct pc_hip_ctx {
 	int last_kernel = -1;          /* pc_hip_last_kernel */
 	int last_run_plain = 0;        /* the last run was pc_hip_transmission_run (its counters tell refl_per_launch) */
 	int producer_new_min = 2, producer_new_first = 6;
+	int march_stats = 0;           /* option "march_stats": the launching-wave kernel counts march steps and their lanes (pc_hip_phase_stats); off in
+	                                * production runs, bench.py switches it on for one extra launch outside the timed steps */
 	int wave_per_photon = 0;       /* EXPERIMENT (pc_wave_kernel.h): 1 = single-energy histogram-only source runs with one wave per photon */
 	int pool = 0;                  /* 1: single-energy source runs on profiles of up to 1024 points use the per-wave photon pool in LDS (pc_pool_kernel.h).
 	                                * Was the default up to v14 (+6 %); since flights take 5.5 steps instead of 8.8 the exchanges with the pool cost more
@@ -1288,7 +1290,8 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 			a.new_threshold = ctx->producer_new_min;
 			a.pool_event_min = ctx->producer_new_first;
 			if (ctx->rec_ev0) PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
-			hipLaunchKernelGGL((pc_trace_producer_kernel<MODE>), dim3(grid), dim3(PC3_BLOCK), 0, ctx->stream, a);
+			if (ctx->march_stats) hipLaunchKernelGGL((pc_trace_producer_kernel<MODE, true>), dim3(grid), dim3(PC3_BLOCK), 0, ctx->stream, a);
+			else hipLaunchKernelGGL((pc_trace_producer_kernel<MODE, false>), dim3(grid), dim3(PC3_BLOCK), 0, ctx->stream, a);
 			ctx->last_kernel = 2;
 			PC_HIP_CHECK(hipGetLastError());
 			if (ctx->rec_ev1) PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
@@ -1476,6 +1479,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "fetch_threads") { if (value < 0 || value > 256) return pc_fail(PC_HIP_ERR_INVALID, "fetch_threads must be in [0,256]"); ctx->fetch_threads = (int)value; }
 	else if (n == "pool") ctx->pool = value ? 1 : 0;
 	else if (n == "wave_per_photon") ctx->wave_per_photon = value ? 1 : 0;
+	else if (n == "march_stats") ctx->march_stats = value ? 1 : 0;
 	else if (n == "cu_share") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "cu_share must be in [1,64]"); ctx->cu_share = (int)value; }
 	else if (n == "producer") { if (value < -1 || value > 1) return pc_fail(PC_HIP_ERR_INVALID, "producer must be -1 (automatic), 0 or 1"); ctx->producer = (int)value; }
 	else if (n == "producer_new_min") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "producer_new_min must be in [1,64]"); ctx->producer_new_min = (int)value; }

@@ -60,7 +60,9 @@ __device__ __forceinline__ void pc3_store(unsigned int *p, unsigned int v)
 	__hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int MODE>
+/* STATS: the march burst counts its steps and their active lanes (pc_hip_phase_stats; option "march_stats").  The production
+ * instantiation leaves those two counters at zero: their ballot + popcount sat inside the unrolled hot loop. */
+template <int MODE, bool STATS = false>
 __global__ void __launch_bounds__(PC3_BLOCK, 4)
 pc_trace_producer_kernel(pc_kargs a)
 {
@@ -387,12 +389,12 @@ pc_trace_producer_kernel(pc_kargs a)
 				unsigned int lanes_in_burst = 0;
 #pragma unroll
 				for (int u = 0; u < PC_MARCH_UNROLL; u++) {
-					lanes_in_burst += (unsigned)__popcll(__ballot(state == LS_MARCH));
+					if (STATS) lanes_in_burst += (unsigned)__popcll(__ballot(state == LS_MARCH));
 					if (state == LS_MARCH)
 						state = pc_march_step_hot(T, Pm, ph);
 				}
 				const int cM = __popcll(__ballot(state == LS_MARCH));
-				st_march += PC_MARCH_UNROLL; st_march_l += lanes_in_burst;
+				if (STATS) { st_march += PC_MARCH_UNROLL; st_march_l += lanes_in_burst; }
 				if (cM == 0) break;
 				if (cM < a.march_stop && (cM != nM || do_new || nE > 0)) break;
 			}

@@ -490,7 +490,9 @@ def test_pool_and_producer_kernels_are_bit_identical(pa, oracle):
                     r = ctx.totals(check=False)
                     r.update(ctx.images(0, n))
                     assert ctx.last_kernel() == {"lane": "pc_trace_kernel", "pool": "pc_trace_pool_kernel", "producer": "pc_trace_producer_kernel"}[name]
-                    assert ctx.phase_stats()["march"]["phases"] > 0
+                    st = ctx.phase_stats()
+                    # (the production instantiation of the launching-wave kernel leaves the march counters alone: option march_stats)
+                    assert st["event"]["phases"] > 0 and (name == "producer" or st["march"]["phases"] > 0)
                     res[name] = r
             a = res["lane"]
             done = a["exit_weights"][:, 0] > 0        # a slot that ran out of attempts has weight 0 and no defined exit planes
