@@ -55,6 +55,7 @@ struct pc_params {
 	int generic_src;    /* src_x != src_y: elliptical source, libm sampling path */
 	double n_shells;
 	double hexscale;    /* 2*cos(pi/6)*(n_shells+1) */
+	double inv_hexscale; /* 1/hexscale, for certificates (outcomes divide by hexscale like the reference) */
 	double adj;         /* certificate margin: see pc_march_ok */
 	double two_rmax;    /* 2 * max_i cap[i] (block certificates) */
 	float adjf, two_rmaxf;  /* the same two, rounded up to float and inflated by PC_MARGIN_INFLATE: pc_march_ok decides in float */

@@ -226,6 +226,7 @@ struct pc_wall {
 	double ext_slope, cap_slope, seg_z, seg_ext, seg_cap;
 	double hx, hy, hz;                 /* intersection with the neighbouring capillary */
 	double d_travel, q_out, r_out;     /* results */
+	double kn_new;                     /* |(kx, ky)| of the capillary (q_new, r_new) being probed */
 };
 
 struct pc_leak_lane {
@@ -344,6 +345,7 @@ PC_HD int pc_wall_begin(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 	W.dist = 0.; W.base = 0.; W.nst = 0; W.step = 0.;
 	W.seg_step = -1; W.seg_slope = -1; W.cool = 0;
 	W.iesc = 0; W.units = 0;
+	W.kn_new = 0.;                     /* mono-capillary: the probed axis is the optic's */
 	return Pm.mono ? PC_LS_WALL_PROBE : PC_LS_WALL_STEP;
 }
 
@@ -359,8 +361,11 @@ PC_HD int pc_wall_begin(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 PC_HD int pc_wall_piece_safe(const pc_params &Pm, double Kx, double Ky, int inside_stack, double x0, double y0, double zrel0,
                              double dx, double dy, double dz, double D, double seg_ext, double es, double seg_cap, double cs)
 {
-	const double zz0 = (es * zrel0 + seg_ext) / Pm.hexscale;
-	const double dzz = es * dz / Pm.hexscale;                 /* d zz / d path */
+	/* a certificate, not an outcome: products with 1/hexscale instead of the reference's quotients, and the closest approach
+	 * of the piece to the cell centre compared without its quotient (the margins are 1e-6 of the cell size, rounding 1e-16) */
+	const double ih = Pm.inv_hexscale;
+	const double zz0 = (es * zrel0 + seg_ext) * ih;
+	const double dzz = es * dz * ih;                          /* d zz / d path */
 	const double r00 = cs * zrel0 + seg_cap;
 	const double u0x = x0 - Kx*zz0, u0y = y0 - Ky*zz0;
 	const double vx = dx - Kx*dzz, vy = dy - Ky*dzz;
@@ -370,13 +375,17 @@ PC_HD int pc_wall_piece_safe(const pc_params &Pm, double Kx, double Ky, int insi
 	if (fabs(u0x) > h0 || fabs(0.5*u0x + PC_COSPI_6*u0y) > h0 || fabs(0.5*u0x - PC_COSPI_6*u0y) > h0) return -1;
 	if (fabs(u1x) > h1 || fabs(0.5*u1x + PC_COSPI_6*u1y) > h1 || fabs(0.5*u1x - PC_COSPI_6*u1y) > h1) return 0;
 	if (inside_stack) {
-		const double vv = vx*vx + vy*vy;
-		double ts = (vv > 0.) ? -(u0x*vx + u0y*vy)/vv : 0.;
-		ts = (ts < 0.) ? 0. : ((ts > D) ? D : ts);
-		const double cxm = u0x + vx*ts, cym = u0y + vy*ts;
+		/* squared distance of the piece u0 + v t, t in [0, D], to the centre: at t = 0 when it moves away, at t = D when the
+		 * foot of the perpendicular lies beyond, else |u0|^2 - (u0.v)^2/|v|^2 -- compared with rmax^2 after multiplying by |v|^2 */
+		const double vv = vx*vx + vy*vy, uv = u0x*vx + u0y*vy, uu = u0x*u0x + u0y*u0y;
 		const double r1 = r00 + cs*dz*D;
 		const double rmax = ((r00 > r1) ? r00 : r1) + margin;
-		if (cxm*cxm + cym*cym < rmax*rmax) return 0;
+		const double rr = rmax*rmax * (1. + 1.e-12);
+		int near;
+		if (!(uv < 0.)) near = uu < rr;                               /* moving away from the centre (or not moving) */
+		else if (-uv >= vv*D) near = (u1x*u1x + u1y*u1y) < rr;         /* still approaching at the end of the piece */
+		else near = (uu*vv - uv*uv) < rr*vv;
+		if (near) return 0;
 	}
 	return 1;
 }
@@ -411,7 +420,9 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 		for (int hop = 0; hop < PC_WALL_HOPS; hop++) {
 			if (!(T.z[z_id] <= W.pz && W.pz < T.z[z_id+1])) break;
 			const double stp = T.cap[z_id]/10.;
-			const double room = (T.z[z_id+1] - W.pz)/(stp*dz);
+			/* candidate block length: checked below against the positions the literal arithmetic produces, so a product with
+			 * reciprocals does (1/dz is the ray's) */
+			const double room = (T.z[z_id+1] - W.pz)*ph.idzd*(10./T.cap[z_id]);
 			/* the block may run up to the last step that still lands inside this segment: the candidate count from the
 			 * division is checked against the position the literal arithmetic would produce there */
 			int m = (room > 1.e6) ? 1000000 : (int)room;
@@ -420,8 +431,8 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 			if (m >= 1 && !(Pz + (b0 + (double)(n0 + m)*stp)*dz < T.z[z_id+1])) m--;
 			if (m >= 1 && !(Pz + (b0 + (double)(n0 + m)*stp)*dz < T.z[z_id+1])) m--;
 			const int m_full = m;
-			const double dzs = T.z[z_id+1] - T.z[z_id];
-			const double es = (T.ext[z_id+1] - T.ext[z_id])/dzs, cs = (T.cap[z_id+1] - T.cap[z_id])/dzs;
+			/* slopes of the certificate: with the tabulated 1/dz */
+			const double es = (T.ext[z_id+1] - T.ext[z_id])*T.idz[z_id], cs = (T.cap[z_id+1] - T.cap[z_id])*T.idz[z_id];
 			int ok = (m == 0);                 /* nothing left inside this segment: only the crossing step remains */
 			for (; m >= 2 && !ok; m = (m == m_full && hop > 0) ? 0 : (m >> 2)) {
 				const double D = (double)m * stp * (1. + 1.e-9);
@@ -446,10 +457,9 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 			const double qd = b1 + (double)(n1 + 1)*stp;
 			const double qz = Pz + qd*dz;                                          /* z of the landing point of the crossing step */
 			if (!(T.z[z_id+1] <= qz && qz < T.z[z_id+2])) break;
-			const double tB = (T.z[z_id+1] - W.pz)/dz * (1. + 1.e-9);            /* path length to the node */
+			const double tB = (T.z[z_id+1] - W.pz)*ph.idzd * (1. + 2.e-9);       /* path length to the node (certificate: product with 1/dz) */
 			if (pc_wall_piece_safe(Pm, Kx, Ky, inside_stack, W.px, W.py, W.pz - T.z[z_id], dx, dy, dz, tB, T.ext[z_id], es, T.cap[z_id], cs) <= 0) break;
-			const double dzn = T.z[z_id+2] - T.z[z_id+1];
-			const double esn = (T.ext[z_id+2] - T.ext[z_id+1])/dzn, csn = (T.cap[z_id+2] - T.cap[z_id+1])/dzn;
+			const double esn = (T.ext[z_id+2] - T.ext[z_id+1])*T.idz[z_id+1], csn = (T.cap[z_id+2] - T.cap[z_id+1])*T.idz[z_id+1];
 			const double bx = Px + (W.dist + tB)*dx, by = Py + (W.dist + tB)*dy;     /* the ray at (just past) the node */
 			const double tQ = (qd - W.dist - tB);
 			if (tQ > 0. && pc_wall_piece_safe(Pm, Kx, Ky, inside_stack, bx, by, 0., dx, dy, dz, tQ * (1. + 1.e-9) + 1.e-12*stp, T.ext[z_id+1], esn, T.cap[z_id+1], csn) <= 0) break;
@@ -511,6 +521,10 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 	/* :1105 on to the wall of capillary (q_new, r_new) */
 	W.iesc = 0;
 	W.hx = Px; W.hy = Py; W.hz = Pz;
+	{
+		const double kx = (2.* W.q_new+W.r_new) * PC_COSPI_6, ky = W.r_new * (3./2);
+		W.kn_new = sqrt(kx*kx + ky*ky);
+	}
 	return PC_LS_WALL_PROBE;
 }
 
@@ -530,7 +544,7 @@ PC_HD int pc_wall_probe(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 	int skipped = 0;
 	if (!Pm.literal) {
 		const int i0 = W.z_id;
-		const double kn = sqrt(probe.kx*probe.kx + probe.ky*probe.ky);
+		const double kn = W.kn_new;        /* set where the probe of this capillary begins: one root per capillary, not per unit */
 		const double z0 = T.z[i0], zh0 = T.zh[i0];
 		const double ax = fma(-probe.kx, zh0, fma(probe.sx, z0, probe.ox));
 		const double ay = fma(-probe.ky, zh0, fma(probe.sy, z0, probe.oy));
@@ -542,10 +556,7 @@ PC_HD int pc_wall_probe(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 			const double bx = fma(-probe.kx, zh1, fma(probe.sx, z1, probe.ox));
 			const double by = fma(-probe.ky, zh1, fma(probe.sy, z1, probe.oy));
 			const double ex = bx - ax, ey = by - ay;
-			const double ee = ex*ex + ey*ey;
-			double t = (ee > 0.) ? -(ax*ex + ay*ey)/ee : 0.;
-			t = (t < 0.) ? 0. : ((t > 1.) ? 1. : t);
-			const double cxm = ax + t*ex, cym = ay + t*ey;
+			const double ee = ex*ex + ey*ey, ae = ax*ex + ay*ey, aa = ax*ax + ay*ay;
 			double reach;
 			if (Ls == 1) {
 				const double r0 = T.cap[i0], r1 = T.cap[i1];
@@ -554,7 +565,15 @@ PC_HD int pc_wall_probe(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 				reach = 0.5*Pm.two_rmax + kn * (double)((lv == 2) ? T.mg[i0].md2 : T.mg[i0].md1);
 			}
 			reach += 1.e-7 * (0.5*Pm.two_rmax);
-			if (cxm*cxm + cym*cym > reach*reach) {
+			/* squared distance of the chord a + e t, t in [0, 1], to the axis, without the quotient of the foot point: at t = 0
+			 * when the chord moves away, at t = 1 when the foot lies beyond, else |a|^2 - (a.e)^2/|e|^2 (compared after
+			 * multiplying by |e|^2; a certificate: 1e-7 of margin against 1e-16 of rounding) */
+			const double rr = reach*reach;
+			int far;
+			if (!(ae < 0.)) far = aa > rr;
+			else if (-ae >= ee) far = (bx*bx + by*by) > rr;
+			else far = (aa*ee - ae*ae) > rr*ee*(1. + 1.e-12);
+			if (far) {
 				W.z_id = i1;
 				W.iesc = -3;
 				skipped = 1;

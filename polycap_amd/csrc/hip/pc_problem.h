@@ -54,6 +54,7 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 	pm.n_energies = (int)p->n_energies;
 	pm.literal = 0;
 	pm.hexscale = 2.*PC_COSPI_6*(pm.n_shells + 1);
+	pm.inv_hexscale = 1.0/pm.hexscale;
 	pm.uniform_illum = (p->src_sigx < 0. || p->src_sigy < 0.) ? 1 : 0;
 	pm.generic_src = (p->src_x == p->src_y) ? 0 : 1;
 	pm.d_source = p->d_source; pm.src_x = p->src_x; pm.src_y = p->src_y;

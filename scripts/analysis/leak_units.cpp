@@ -1,0 +1,63 @@
+/* Analysis tool (not part of the product or the tests): units of work per exit-photon slot of a leak_calc=true run, by class
+ * (march steps, wall steps, capillary probes, bookkeeping), on the host compile of the device headers -- which slots make the
+ * ~250 ms floor of the leak kernel, and out of what.  Built and driven by scripts/analysis/leak_units.py. */
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "pc_problem.h"
+#include "pc_leak.h"
+
+extern "C" int leak_units(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int64_t n_slots, int max_depth,
+                          int64_t *per_slot /* [n_slots][6]: march, wall step, probe, other units, attempts, deepest level */)
+{
+	pc_host_tables t; std::string err;
+	if (pc_build_tables(p, t, err)) return 1;
+	pc_tables T;
+	T.z = t.z.data(); T.cap = t.cap.data(); T.zh = t.zh.data(); T.cap2 = t.cap2.data(); T.hexd = t.hexd.data(); T.idz = t.idz.data(); T.ext = t.ext.data();
+	T.mg = t.mg.data();
+	const pc_params &Pm = t.pm;
+	const int ne = (int)p->n_energies;
+#pragma omp parallel
+	{
+		std::vector<double> frames((size_t)max_depth * (PC_LF_HDR + ne));
+		std::vector<double> records((size_t)4096 * (PC_LR_HDR + ne));
+		unsigned long long cursor = 0;
+		pc_leak_lane L;
+		pc_leak_ctx &cx = L.cx;
+		pc_photon<0> &ph = L.ph;
+		cx.ec = t.ec.data(); cx.amu = t.amu.data(); cx.ne = ne;
+		cx.frames = frames.data(); cx.max_depth = max_depth;
+		cx.sink.records = records.data(); cx.sink.cursor = &cursor; cx.sink.capacity = 0;      /* events are counted, not kept */
+		cx.stack_overflow = 0;
+#pragma omp for schedule(dynamic, 16)
+		for (int64_t j = 0; j < n_slots; j++) {
+			int64_t *o = per_slot + 6*j;
+			memset(o, 0, 6*sizeof(int64_t));
+			for (uint32_t attempt = 0; attempt < (1u << 20); attempt++) {
+				pc_start s;
+				if (Pm.generic_src) pc_sample_photon<true>(Pm, seed, (uint64_t)(slot0 + j), attempt, s);
+				else pc_sample_photon<false>(Pm, seed, (uint64_t)(slot0 + j), attempt, s);
+				ph.wmem = nullptr; ph.wstride = 1;
+				int st = pc_launch_init(T, Pm, ph, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez);
+				cx.slot = (double)(slot0 + j); cx.attempt = (double)attempt;
+				pc_leak_begin(T, Pm, L, st, s.z);
+				while (L.st != PC_LS_DONE) {
+					if (L.lvl > o[5]) o[5] = L.lvl;
+					if (L.st == PC_LS_MARCH) { o[0]++; pc_leak_unit_march(T, Pm, L); }
+					else if (L.st == PC_LS_WALL_STEP) { o[1]++; L.st = pc_wall_step(T, Pm, L, L.after_wall); }
+					else if (L.st == PC_LS_WALL_PROBE) { o[2]++; L.st = pc_wall_probe(T, Pm, L, L.after_wall); }
+					else { o[3]++; pc_leak_unit_other(T, Pm, L); }
+				}
+				o[4]++;
+				if (L.rc == 1 && pc_in_exit_window(Pm, ph)) break;
+			}
+		}
+	}
+	return 0;
+}

@@ -1,0 +1,37 @@
+"""Units of work per slot of the leak bench workload (scripts/bench_leak.py: the reference's ellipsoidal test optic, uniform
+illumination, 10 keV) on the host compile of the device headers:  python scripts/analysis/leak_units.py [slots]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import polycap_amd
+from polycap_amd.decks import optical_constants
+from polycap_amd import capi
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+so = "/tmp/libleak_units.so"
+subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                       "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "polycap_amd", "csrc", "hip"),
+                       os.path.join(ROOT, "scripts", "analysis", "leak_units.cpp"), "-o", so])
+L = C.CDLL(so)
+prof = capi.Profile(capi.Profile.ELLIPSOIDAL, 9., 0.2065, 0.0585, 0.00035, 9.9153e-5, 1000., 0.5)
+z, cap, ext = prof.get_z(), prof.get_cap(), prof.get_ext()
+a, s, _ = optical_constants([8, 14], [0.53, 0.47], 2.23, [10.0])
+prob = polycap_amd.Problem(z, cap, ext, 0.0, 200000, 2.23, [10.0], a, s, 2000.0, 0.2065, 0.2065, -1.0, 0.0, 0.0, 0.0, 0.5)
+out = np.zeros((n, 6), dtype=np.int64)
+L.leak_units.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
+rc = L.leak_units(C.byref(prob.s), 20000, 0, n, 532, out.ctypes.data)
+assert rc == 0
+tot = out[:, :4].sum(axis=1)
+print("%d slots: units per slot mean %.0f median %.0f p99 %.0f max %d; attempts per slot %.2f" % (n, tot.mean(), np.median(tot), np.percentile(tot, 99), tot.max(), out[:, 4].mean()))
+print("share of all units: march %.2f wall step %.2f probe %.2f other %.2f" % tuple(out[:, k].sum() / tot.sum() for k in range(4)))
+order = np.argsort(-tot)[:10]
+print("the ten heaviest slots: slot, units (march, wall step, probe, other), attempts, deepest level")
+for j in order:
+    print("  %7d %9d (%8d %8d %8d %8d) %3d %4d" % (j, tot[j], out[j, 0], out[j, 1], out[j, 2], out[j, 3], out[j, 4], out[j, 5]))
+print("share of the total in the heaviest 1 %% of the slots: %.2f; the heaviest slot alone is %.1f x the mean" % (np.sort(tot)[-max(1, n // 100):].sum() / tot.sum(), tot.max() / tot.mean()))
