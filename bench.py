@@ -215,10 +215,10 @@ def main():
                          "traffic": (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 if pmc else None,
                          "kernel": {"pc_trace_kernel": "pc_trace_kernel<1,0,1024>"}.get(kernel, kernel + "<0>"), "kernel_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "fp64-VALU/divergence-bound by construction (SURVEY 8d): 144 B per exit photon; traffic and the "
-                                 "VALU counters come from the committed rocprofv3 --pmc summary of this command (FETCH_SIZE + "
-                                 "WRITE_SIZE in KB, raw: the guide's gfx950 x2 correction is calibrated for 16-B-per-lane streaming "
-                                 "reads, this kernel writes 8-B words and reloads scratch), kernel_ms is measured live",
+                         "note": "fp64-VALU/divergence-bound by construction (SURVEY 8d): 144 B per exit photon, written once in coalesced "
+                                 "runs (compact store); traffic and the VALU counters come from the committed rocprofv3 --pmc summary "
+                                 "of this command (FETCH_SIZE + WRITE_SIZE in KB, raw: the guide's gfx950 x2 correction applies to "
+                                 "16-B-per-lane streaming reads, this kernel's traffic is 8-B-per-lane stores), kernel_ms is measured live",
                          "valu_fp64": valu, "valu_issue": valu_issue(pmc, avg_ms)},
         }
         if world == 1 and not args.no_extras:
