@@ -1156,6 +1156,9 @@ struct pc_hip_ctx {
 	unsigned long long *d_leak_cursor = nullptr;
 	double *d_amu = nullptr;
 	unsigned int *d_leak_attempts = nullptr;
+	unsigned long long *d_leak_timing = nullptr;   /* POLYCAP_LEAK_TIMING diagnostics */
+	size_t leak_timing_bytes = 0;
+	long long leak_timing_waves = 0;
 	long long leak_attempt_slots = 0;
 	int leak_pending = 0;                  /* a leak transmission run is in flight: wait() collects its events */
 	unsigned long long leak_seed = 0;
@@ -1394,6 +1397,7 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->d_leak_cursor) (void)hipFree(ctx->d_leak_cursor);
 	if (ctx->d_amu) (void)hipFree(ctx->d_amu);
 	if (ctx->d_leak_attempts) (void)hipFree(ctx->d_leak_attempts);
+	if (ctx->d_leak_timing) (void)hipFree(ctx->d_leak_timing);
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -117,6 +117,14 @@ PC_HD int pc_node_follow(const pc_tables &T, int upto, int z_id, double zval)
 	return z_id;
 }
 
+/* analysis builds (scripts/analysis/leak_units.cpp) count what the units of the wall search end as */
+#ifdef PC_LEAK_STATS
+extern long long pc_leak_stats[16];
+#define PC_LSTAT(k) (__atomic_fetch_add(&pc_leak_stats[k], 1, __ATOMIC_RELAXED))
+#else
+#define PC_LSTAT(k) ((void)0)
+#endif
+
 /* ------------------------------------------------------------------ src/polycap-photon.c:171-362
  * Where the ray that ended at (cx, cy, cz) outside the optic crossed its outer hexagon, searched backwards.
  * Returns 0 where the reference returns NULL. */
@@ -135,8 +143,42 @@ PC_HD int pc_outer_intersect(const pc_tables &T, const pc_params &Pm, double cx,
 	int dir;
 	if (bz < 0.) { z_id = z_id + 1; dir = -1; } else { dir = 1; }
 	int broke = 0;
+	PC_LSTAT(10);
+	/* ---- certified skipping.  The scan looks for the first node where the ray is not outside the hexagon any more; from the
+	 * side of the optic back to that node it is often a hundred nodes.  The ray is linear in z and ext (= zh * hexscale) stays
+	 * within hexscale*md_L of its chord over L segments (pc_marg4), so when at both end nodes of a block the same edge of the
+	 * hexagon is exceeded by more than cos30*hexscale*md_L (+ margin), every node of the block tests "outside" (and has a
+	 * positive ext): the block is passed without visiting its nodes. */
+	const double ibz = 1./bz;
+	int cool = 0;
 	for (;;) {
+		if (!Pm.literal && here == 0 && cool == 0) {
+			int did = 0;
+			for (int lv = 2; lv >= 1 && !did; lv--) {
+				const int Lb = (lv == 2) ? PC_L2 : PC_L1;
+				const int ia = (dir < 0) ? z_id - Lb : z_id, ib = ia + Lb;      /* nodes ia .. ib; z_id itself lies behind */
+				if (ia < 0 || ib > nmax) continue;
+				const double dev = Pm.hexscale * (double)((lv == 2) ? T.mg[ia].md2 : T.mg[ia].md1) * (1. + 1.e-6);
+				const double ea = T.ext[ia], eb = T.ext[ib];
+				if (!(ea > dev && eb > dev)) continue;
+				const double ta = (T.z[ia] - cz)*ibz, tb = (T.z[ib] - cz)*ibz;
+				const double xa = cx + bx*ta, ya = cy + by*ta, xb = cx + bx*tb, yb = cy + by*tb;
+				const double m = PC_COSPI_6*dev + 1.e-9*((ea > eb) ? ea : eb);
+				const double da = T.hexd[ia] + m, db = T.hexd[ib] + m;
+				const double s2a = PC_COSPI_6*xa + 0.5*ya, s2b = PC_COSPI_6*xb + 0.5*yb;
+				const double s3a = PC_COSPI_6*xa - 0.5*ya, s3b = PC_COSPI_6*xb - 0.5*yb;
+				if ((ya > da && yb > db) || (-ya > da && -yb > db) || (s2a > da && s2b > db) || (-s2a > da && -s2b > db)
+				    || (s3a > da && s3b > db) || (-s3a > da && -s3b > db)) {
+					z_id = (dir < 0) ? ia : ib;
+					did = 1;
+				}
+			}
+			if (did) { PC_LSTAT(12); continue; }
+			cool = PC_L1;
+		}
+		if (cool > 0) cool--;
 		z_id += dir;
+		PC_LSTAT(11);
 		if (z_id < 0 || z_id > nmax) break;     /* the reference reads past the profile here; nothing can be found there */
 		double t = (T.z[z_id] - cz);
 		double tx = cx + bx * t / bz;
@@ -346,9 +388,13 @@ PC_HD int pc_wall_begin(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 	W.seg_step = -1; W.seg_slope = -1; W.cool = 0;
 	W.iesc = 0; W.units = 0;
 	W.kn_new = 0.;                     /* mono-capillary: the probed axis is the optic's */
+	PC_LSTAT(8);
 	return Pm.mono ? PC_LS_WALL_PROBE : PC_LS_WALL_STEP;
 }
 
+#ifndef PC_PROBE_BLOCKS
+#define PC_PROBE_BLOCKS 4  /* certified blocks of segments one unit of the capillary probe may skip */
+#endif
 #ifndef PC_WALL_HOPS
 #define PC_WALL_HOPS 1     /* profile segments one unit of the wall search may cross; measured on MI355X (scripts/ab_leak.sh): 1 -> 515 ms, 2 -> 558, 4 -> 606, 8 -> 630 for 262144 slots: longer units diverge more inside the wave than they save */
 #endif
@@ -417,6 +463,70 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 		const int inside_stack = (fabs(W.q_i) <= ns && fabs(W.r_i) <= ns && fabs(-1.*W.q_i-W.r_i) <= ns);
 		const double Kx = (2.*W.q_i + W.r_i) * PC_COSPI_6, Ky = W.r_i * 1.5;
 		int advanced = 0;
+		/* ---- blocks of PC_L2 / PC_L1 segments.  Over L segments zh stays within md_L (tabulated, pc_marg4) of the chord between
+		 * its two end nodes, so u = p - K*zh stays within |K| md_L of the straight line between its two end values taken with
+		 * the chord, and the cell's inradius within cos30 md_L of the chord's: the hexagon tests hold on the whole block if they
+		 * hold at both ends with (|K| + cos30) md_L taken off (|n.u| convex, the bound linear), and the capillary (never wider
+		 * than the block's largest radius, r2/2) is not met when the line's closest approach to the cell centre is farther than
+		 * r2/2 + |K| md_L.  Then no literal step that lands before the end of the block can leave the loop, and only the count
+		 * of steps per segment -- exactly the literal arithmetic's -- is carried out. */
+		if (T.z[z_id] <= W.pz && W.pz < T.z[z_id+1]) {
+			const double kab = fabs(Kx) + fabs(Ky);          /* >= |K| */
+			const pc_marg4 g = T.mg[z_id];
+			for (int lv = 2; lv >= 1 && !advanced; lv--) {
+				const int i1 = z_id + ((lv == 2) ? PC_L2 : PC_L1);
+				if (i1 > nmax-1) continue;
+				const double md = (double)((lv == 2) ? g.md2 : g.md1);
+				const double zA = T.z[z_id], zB = T.z[i1], zhA = T.zh[z_id], zhB = T.zh[i1];
+				const double zha = zhA + (zhB - zhA)*((W.pz - zA)/(zB - zA));      /* the chord at the current point */
+				const double tB = (zB - W.pz)*ph.idzd;
+				const double ubx = (W.px + tB*dx) - Kx*zhB, uby = (W.py + tB*dy) - Ky*zhB;
+				const double uax = W.px - Kx*zha, uay = W.py - Ky*zha;
+				const double margin = 1.e-6 * zha;
+				const double dev = (PC_COSPI_6 + kab)*md*(1. + 1.e-6) + margin;
+				const double ha = PC_COSPI_6*zha - dev, hb = PC_COSPI_6*zhB - dev;
+				if (fabs(uax) > ha || fabs(0.5*uax + PC_COSPI_6*uay) > ha || fabs(0.5*uax - PC_COSPI_6*uay) > ha) continue;
+				if (fabs(ubx) > hb || fabs(0.5*ubx + PC_COSPI_6*uby) > hb || fabs(0.5*ubx - PC_COSPI_6*uby) > hb) continue;
+				if (inside_stack) {
+					const double ex = ubx - uax, ey = uby - uay;
+					const double ee = ex*ex + ey*ey, ae = uax*ex + uay*ey, aa = uax*uax + uay*uay;
+					const double reach = 0.5*(double)g.r2 + kab*md*(1. + 1.e-6) + margin;
+					const double rr = reach*reach*(1. + 1.e-12);
+					int far;
+					if (!(ae < 0.)) far = aa > rr;
+					else if (-ae >= ee) far = (ubx*ubx + uby*uby) > rr;
+					else far = (aa*ee - ae*ae) > rr*ee;
+					if (!far) continue;
+				}
+				/* certified up to zB: per segment the steps that land inside it and the one that crosses its end */
+				for (int guard = 0; z_id < i1 && guard < 4*PC_L2; guard++) {
+					const double stp = T.cap[z_id]/10.;
+					const double z1 = T.z[z_id+1];
+					const double room = (z1 - W.pz)*ph.idzd*(10./T.cap[z_id]);
+					int m = (room > 1.e6) ? 1000000 : (int)room;
+					if (m < 0) m = 0;
+					const long long n0 = (z_id != W.seg_step) ? 0 : W.nst;
+					const double b0 = (z_id != W.seg_step) ? W.dist : W.base;
+					if (m >= 1 && !(Pz + (b0 + (double)(n0 + m)*stp)*dz < z1)) m--;
+					if (m >= 1 && !(Pz + (b0 + (double)(n0 + m)*stp)*dz < z1)) m--;
+					int steps = m + 1, last = 0;
+					if (!(Pz + (b0 + (double)(n0 + steps)*stp)*dz < zB)) { steps = m; last = 1; }
+					if (steps > 0) {
+						if (z_id != W.seg_step) { W.seg_step = z_id; W.step = stp; W.base = W.dist; W.nst = 0; }
+						W.nst += steps;
+						W.dist = W.base + (double)W.nst*W.step;
+						W.px = Px + W.dist*dx;
+						W.py = Py + W.dist*dy;
+						W.pz = Pz + W.dist*dz;
+						z_id = pc_node_follow(T, nmax, z_id, W.pz);
+						advanced = 1;
+					}
+					if (last || steps == 0) break;
+				}
+				W.z_id = z_id;
+			}
+			if (advanced) { PC_LSTAT(9); return PC_LS_WALL_STEP; }
+		}
 		for (int hop = 0; hop < PC_WALL_HOPS; hop++) {
 			if (!(T.z[z_id] <= W.pz && W.pz < T.z[z_id+1])) break;
 			const double stp = T.cap[z_id]/10.;
@@ -473,10 +583,11 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 			W.z_id = z_id;
 			advanced = 1;
 		}
-		if (advanced) return PC_LS_WALL_STEP;
+		if (advanced) { PC_LSTAT(0); return PC_LS_WALL_STEP; }
 		W.cool = 1;      /* a cell edge or the capillary is within a step or two: one literal step, then try again */
 	}
 	if (W.cool > 0) W.cool--;
+	PC_LSTAT(1);
 
 	/* ---- one literal step.  dist = base + nst*step: the path length after nst steps of the current size (the reference
 	 * adds the steps one by one; the product differs from that sum by rounding only and lets a block be skipped in O(1)) */
@@ -521,6 +632,7 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 	/* :1105 on to the wall of capillary (q_new, r_new) */
 	W.iesc = 0;
 	W.hx = Px; W.hy = Py; W.hz = Pz;
+	PC_LSTAT(2);
 	{
 		const double kx = (2.* W.q_new+W.r_new) * PC_COSPI_6, ky = W.r_new * (3./2);
 		W.kn_new = sqrt(kx*kx + ky*ky);
@@ -538,13 +650,16 @@ PC_HD int pc_wall_probe(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 	else { probe.ky = W.r_new * (3./2); probe.kx = (2.* W.q_new+W.r_new) * PC_COSPI_6; }
 	/* ---- certain misses.  Relative to the axis of the probed capillary the ray is q(z) = p(z) - K*zh(z).  Over L segments
 	 * q stays within kn*md_L of the chord between its two end values (md_L: tabulated chord deviation of zh, 0 for L = 1)
-	 * and the radius never exceeds Rmax, so when the chord's closest approach to the axis is farther than
-	 * Rmax + kn*md_L (+ margin) the ray is outside the capillary on all L segments: the reference's quadratic
-	 * (src/polycap-capil.c:119-171) has no root inside any of them and every one of the L visits is a miss. */
+	 * and the radius never exceeds R_blk (the largest of the block, pc_marg4::r2 / 2), so when the chord's closest approach to
+	 * the axis is farther than R_blk + kn*md_L (+ margin) the ray is outside the capillary on all L segments: the reference's
+	 * quadratic (src/polycap-capil.c:119-171) has no root inside any of them and every one of the L visits is a miss.  A unit
+	 * takes up to PC_PROBE_BLOCKS such blocks. */
 	int skipped = 0;
-	if (!Pm.literal) {
+	for (int blk = 0; blk < (Pm.literal ? 0 : PC_PROBE_BLOCKS); blk++) {
+		skipped = 0;
 		const int i0 = W.z_id;
 		const double kn = W.kn_new;        /* set where the probe of this capillary begins: one root per capillary, not per unit */
+		const pc_marg4 g = T.mg[i0];
 		const double z0 = T.z[i0], zh0 = T.zh[i0];
 		const double ax = fma(-probe.kx, zh0, fma(probe.sx, z0, probe.ox));
 		const double ay = fma(-probe.ky, zh0, fma(probe.sy, z0, probe.oy));
@@ -562,7 +677,7 @@ PC_HD int pc_wall_probe(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 				const double r0 = T.cap[i0], r1 = T.cap[i1];
 				reach = (r0 > r1) ? r0 : r1;
 			} else {
-				reach = 0.5*Pm.two_rmax + kn * (double)((lv == 2) ? T.mg[i0].md2 : T.mg[i0].md1);
+				reach = 0.5*(double)g.r2 + kn * (double)((lv == 2) ? g.md2 : g.md1);
 			}
 			reach += 1.e-7 * (0.5*Pm.two_rmax);
 			/* squared distance of the chord a + e t, t in [0, 1], to the axis, without the quotient of the foot point: at t = 0
@@ -577,12 +692,15 @@ PC_HD int pc_wall_probe(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 				W.z_id = i1;
 				W.iesc = -3;
 				skipped = 1;
+				PC_LSTAT(3 + lv);
 			}
 		}
+		if (!skipped || W.z_id >= nmax-1) break;
 	}
 	if (!skipped) {
 		double p0x, p0y, nx, ny, nz;
 		W.iesc = pc_segment(T, probe, W.z_id, p0x, p0y, W.hx, W.hy, W.hz, nx, ny, nz);
+		PC_LSTAT(W.iesc == 1 ? 7 : 6);
 		W.z_id++;
 	}
 	if (W.iesc != 1 && W.z_id < nmax-1)

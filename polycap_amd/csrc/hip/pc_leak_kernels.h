@@ -31,6 +31,7 @@ struct pc_leak_kargs {
 	unsigned long long *cursor;    /* [0] records appended, [1] lanes whose stack overflowed */
 	long long capacity;
 	unsigned int *final_attempt;   /* [n_slots]: attempt index of the transmitted photon of each slot (driver mode) */
+	unsigned long long *timing;    /* diagnostics (POLYCAP_LEAK_TIMING): 8 clock sums per wave, or null */
 };
 
 /* lane modes of the scheduler on top of pc_leak_lane::st */
@@ -85,7 +86,16 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 	unsigned long long s_irefl = 0;
 	unsigned long long st_units[4] = {0, 0, 0, 0}, st_lanes[4] = {0, 0, 0, 0};   /* scheduler statistics per class */
 
+	unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_first_idle = 0;
+	const unsigned long long t_begin = lk.timing ? wall_clock64() : 0ull;
+	unsigned long long t_last = t_begin;
+	int cls = 5;
 	for (;;) {
+		if (lk.timing) {
+			const unsigned long long now = wall_clock64();
+			tk[cls] += now - t_last; t_last = now;
+			if (t_first_idle == 0 && __ballot(mode == PC_LM_IDLE) != 0ull) t_first_idle = now - t_begin;
+		}
 		if (mode == PC_LM_RUN && L.st == PC_LS_DONE) { mode = PC_LM_NEED; launched = 1; }
 		const unsigned long long mM = __ballot(mode == PC_LM_RUN && L.st == PC_LS_MARCH);
 		const unsigned long long mS = __ballot(mode == PC_LM_RUN && L.st == PC_LS_WALL_STEP);
@@ -98,6 +108,7 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 		const int best = max(max(nM, nS), max(nP, 2*max(nO, nN)));
 		if (nS > 0 && nS == best) {
 			/* ---- wall search: blocks / steps through the glass */
+			cls = 0;
 			const int stop = (nS + 1) / 2;
 			for (int b = 0; b < 32; b++) {
 				if (mode == PC_LM_RUN && L.st == PC_LS_WALL_STEP)
@@ -108,6 +119,7 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 			}
 		} else if (nP > 0 && nP == best) {
 			/* ---- wall search: segments of the neighbouring capillary */
+			cls = 1;
 			const int stop = (nP + 1) / 2;
 			for (int b = 0; b < 32; b++) {
 				if (mode == PC_LM_RUN && L.st == PC_LS_WALL_PROBE)
@@ -118,6 +130,7 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 			}
 		} else if (nM > 0 && nM == best) {
 			/* ---- certified march between interactions */
+			cls = 2;
 			const int stop = (nM + 1) / 2;
 			for (int b = 0; b < 32; b++) {
 				if (mode == PC_LM_RUN && L.st == PC_LS_MARCH)
@@ -128,11 +141,13 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 			}
 		} else if (nO > 0 && nO >= nN) {
 			/* ---- segment visits, reflections with their leak bookkeeping, end of a photon */
+			cls = 3;
 			st_units[3]++; st_lanes[3] += (unsigned)nO;
 			if (mode == PC_LM_RUN && L.st != PC_LS_MARCH && L.st != PC_LS_WALL_STEP && L.st != PC_LS_WALL_PROBE)
 				pc_leak_unit_other(T, Pm, L);
 		} else {
 			/* ---- driver: verdict on finished launches, next attempt or next slot */
+			cls = 4;
 			if (mode == PC_LM_NEED) {
 				int need_slot = 1;
 				if (launched) {
@@ -236,6 +251,11 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 		}
 	}
 
+	if (lk.timing && lane == 0) {
+		unsigned long long *o = lk.timing + 8*(gtid / PC_WAVE);
+		for (int k = 0; k < 5; k++) o[k] = tk[k];
+		o[5] = wall_clock64() - t_begin; o[6] = t_first_idle; o[7] = t_begin;
+	}
 	if (L.cx.stack_overflow) atomicAdd(&lk.cursor[1], 1ull);
 	if (!EXPLICIT) {
 		unsigned long long v0 = pc_wave_sum_u64(n_exit), v1 = pc_wave_sum_u64(n_not_entered), v2 = pc_wave_sum_u64(n_not_trans);
@@ -322,6 +342,16 @@ static int pc_leak_enqueue(pc_hip_ctx *ctx, pc_kargs &a, long long n_items, long
 	lk.amu = ctx->d_amu; lk.frames = ctx->d_leak_frames; lk.max_depth = ctx->leak_max_depth;
 	lk.records = ctx->d_leak_records; lk.cursor = ctx->d_leak_cursor; lk.capacity = capacity;
 	lk.final_attempt = ctx->d_leak_attempts;
+	lk.timing = nullptr;
+	if (getenv("POLYCAP_LEAK_TIMING")) {
+		/* diagnostics: where the waves of the leak kernel spend their time (printed by pc_leak_collect) */
+		const size_t nb = (size_t)(lanes / PC_WAVE) * 8 * sizeof(unsigned long long);
+		if (ctx->d_leak_timing && ctx->leak_timing_bytes < nb) { (void)hipFree(ctx->d_leak_timing); ctx->d_leak_timing = nullptr; }
+		if (!ctx->d_leak_timing) { PC_HIP_CHECK(hipMalloc(&ctx->d_leak_timing, nb)); ctx->leak_timing_bytes = nb; }
+		PC_HIP_CHECK(hipMemsetAsync(ctx->d_leak_timing, 0, nb, ctx->stream));
+		lk.timing = ctx->d_leak_timing;
+		ctx->leak_timing_waves = lanes / PC_WAVE;
+	}
 	a.total_threads = lanes;
 	PC_HIP_CHECK(hipMemsetAsync(ctx->d_leak_cursor, 0, 2*sizeof(unsigned long long), ctx->stream));
 	PC_HIP_CHECK(hipMemsetAsync(ctx->d_totals, 0, ctx->totals_bytes, ctx->stream));
@@ -344,6 +374,28 @@ static int pc_leak_collect(pc_hip_ctx *ctx, long long n_slots, bool explicit_mod
 	unsigned long long cur[2] = {0, 0};
 	PC_HIP_CHECK(hipMemcpy(cur, ctx->d_leak_cursor, sizeof(cur), hipMemcpyDeviceToHost));
 	ctx->leak_ext.clear(); ctx->leak_int.clear();
+	if (ctx->d_leak_timing && getenv("POLYCAP_LEAK_TIMING")) {
+		const size_t nw = (size_t)ctx->leak_timing_waves;
+		std::vector<unsigned long long> t(nw*8);
+		PC_HIP_CHECK(hipMemcpy(t.data(), ctx->d_leak_timing, nw*8*sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		double sum[8] = {0}, mx[8] = {0}; size_t ran = 0;
+		unsigned long long t0 = ~0ull, t1 = 0;
+		for (size_t w = 0; w < nw; w++) {
+			if (t[w*8+5] == 0) continue;
+			ran++;
+			for (int k = 0; k < 7; k++) { sum[k] += (double)t[w*8+k]; if ((double)t[w*8+k] > mx[k]) mx[k] = (double)t[w*8+k]; }
+			if (t[w*8+7] < t0) t0 = t[w*8+7];
+			if (t[w*8+7] + t[w*8+5] > t1) t1 = t[w*8+7] + t[w*8+5];
+		}
+		std::vector<unsigned long long> life;
+		for (size_t w = 0; w < nw; w++) if (t[w*8+5]) life.push_back(t[w*8+5]);
+		std::sort(life.begin(), life.end());
+		const double tick = 1e-5;     /* wall_clock64: 100 MHz -> ms */
+		fprintf(stderr, "leak timing: %zu waves ran; span %.1f ms; per wave mean (max) in ms: wall %.1f (%.1f) probe %.1f (%.1f) march %.1f (%.1f) other %.1f (%.1f) driver %.1f (%.1f) | life %.1f (%.1f) median %.1f p90 %.1f | first idle lane after %.1f (%.1f)\n",
+		        ran, (double)(t1 - t0)*tick, sum[0]/ran*tick, mx[0]*tick, sum[1]/ran*tick, mx[1]*tick, sum[2]/ran*tick, mx[2]*tick, sum[3]/ran*tick, mx[3]*tick,
+		        sum[4]/ran*tick, mx[4]*tick, sum[5]/ran*tick, mx[5]*tick, life.empty() ? 0. : (double)life[life.size()/2]*tick, life.empty() ? 0. : (double)life[life.size()*9/10]*tick,
+		        sum[6]/ran*tick, mx[6]*tick);
+	}
 	ctx->leak_n_ext = ctx->leak_n_int = 0;
 	if (cur[1] != 0)
 		return pc_fail(PC_HIP_ERR_RUNTIME, "leak run: the chain of wall crossings was deeper than leak_max_depth for " + std::to_string(cur[1]) + " lane(s); raise the option leak_max_depth");

@@ -10,8 +10,12 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+#define PC_LEAK_STATS 1
 #include "pc_problem.h"
 #include "pc_leak.h"
+
+long long pc_leak_stats[16];
+extern "C" long long *leak_stats(void) { return pc_leak_stats; }
 
 extern "C" int leak_units(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int64_t n_slots, int max_depth,
                           int64_t *per_slot /* [n_slots][6]: march, wall step, probe, other units, attempts, deepest level */)
