@@ -72,6 +72,9 @@ struct pc_params {
  * r2 = twice the largest capillary radius of the PC_L2 block (which contains the PC_L1 block).  All rounded up and, except the
  * deviations, inflated by PC_MARGIN_INFLATE at build time (pc_problem.h). */
 struct pc_marg4 { unsigned int mb12; float md1, md2, r2; };
+/* leak path: chord deviations of cap over the PC_L1 / PC_L2 block that starts at a node, rounded up (infinite where the block
+ * does not fit) */
+struct pc_drdev { float d1, d2; };
 
 PC_HD float pc_bits_as_float(unsigned int u) { return __builtin_bit_cast(float, u); }
 
@@ -84,6 +87,9 @@ struct pc_tables {
 	const double *hexd;  /* sqrt(ext^2 - (ext/2)^2): centre-to-edge distance of the outer hexagon at node i */
 	const double *idz;   /* 1 / (z[i+1] - z[i]) */
 	const double *ext;
+	const double *stp;   /* leak path: cap[i] / 10, the step of the wall search in segment i (src/polycap-capil.c:1019) */
+	const double *istp;  /* leak path: 10 / cap[i] (candidates for step counts only) */
+	const struct pc_drdev *dr;   /* leak path: chord deviations of cap */
 	/* block certificates (see pc_march_ok): for stride L1 / L2, margin base and chord deviation of zh, rounded up */
 	const struct pc_marg4 *mg;   /* margin base and chord deviation of zh of both strides, packed per start node: one 16-byte read */
 };

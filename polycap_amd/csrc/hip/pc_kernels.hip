@@ -88,7 +88,7 @@ struct pc_totals {             /* device-resident totals of one run */
 };
 
 struct pc_kargs {
-	const double *g_z, *g_cap, *g_zh, *g_cap2, *g_hexd, *g_idz, *g_ext;
+	const double *g_z, *g_cap, *g_zh, *g_cap2, *g_hexd, *g_idz, *g_ext, *g_stp, *g_istp;
 	const pc_marg4 *g_mg;         /* block-certificate record per start node (pc_problem.h) */
 	const pc_energy_const *ec;
 	const double *ec_soa;         /* the same constants field-major [6][n_energies]: coalesced loads in the cooperative sweeps */
@@ -1181,7 +1181,7 @@ static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
 	memset(&a, 0, sizeof(a));
 	a.g_z = ctx->d_tables; a.g_cap = ctx->d_tables + npts; a.g_zh = ctx->d_tables + 2*npts;
 	a.g_cap2 = ctx->d_tables + 3*npts; a.g_hexd = ctx->d_tables + 4*npts; a.g_idz = ctx->d_tables + 5*npts;
-	a.g_ext = ctx->d_tables + 6*npts;
+	a.g_ext = ctx->d_tables + 6*npts; a.g_stp = ctx->d_tables + 7*npts; a.g_istp = ctx->d_tables + 8*npts;
 	a.g_mg = ctx->d_mg;
 	a.ec = ctx->d_ec;
 	a.ec_soa = ctx->d_ec_soa;
@@ -1428,9 +1428,10 @@ int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ou
 		if (*e == '0' || *e == '1') ctx->producer = *e - '0';
 	PC_CTX_CHECK(hipEventCreate(&ctx->ev0));
 	PC_CTX_CHECK(hipEventCreate(&ctx->ev1));
-	PC_CTX_CHECK(hipMalloc(&ctx->d_tables, 7*npts*sizeof(double)));
-	const std::vector<double> *src[7] = { &ctx->host.z, &ctx->host.cap, &ctx->host.zh, &ctx->host.cap2, &ctx->host.hexd, &ctx->host.idz, &ctx->host.ext };
-	for (int k = 0; k < 7; k++)
+	PC_CTX_CHECK(hipMalloc(&ctx->d_tables, 9*npts*sizeof(double)));
+	const std::vector<double> *src[9] = { &ctx->host.z, &ctx->host.cap, &ctx->host.zh, &ctx->host.cap2, &ctx->host.hexd, &ctx->host.idz, &ctx->host.ext,
+	                                      &ctx->host.stp, &ctx->host.istp };
+	for (int k = 0; k < 9; k++)
 		PC_CTX_CHECK(hipMemcpy(ctx->d_tables + k*npts, src[k]->data(), npts*sizeof(double), hipMemcpyHostToDevice));
 	PC_CTX_CHECK(hipMalloc(&ctx->d_mg, npts*sizeof(pc_marg4)));
 	PC_CTX_CHECK(hipMemcpy(ctx->d_mg, ctx->host.mg.data(), npts*sizeof(pc_marg4), hipMemcpyHostToDevice));

@@ -395,45 +395,48 @@ PC_HD int pc_wall_begin(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 #ifndef PC_PROBE_BLOCKS
 #define PC_PROBE_BLOCKS 4  /* certified blocks of segments one unit of the capillary probe may skip */
 #endif
-#ifndef PC_WALL_HOPS
-#define PC_WALL_HOPS 1     /* profile segments one unit of the wall search may cross; measured on MI355X (scripts/ab_leak.sh): 1 -> 515 ms, 2 -> 558, 4 -> 606, 8 -> 630 for 262144 slots: longer units diverge more inside the wave than they save */
+#ifndef PC_WALL_PIECES
+#define PC_WALL_PIECES 3   /* straight pieces (blocks of 1, PC_L1 or PC_L2 segments) one unit of the wall search may certify */
 #endif
 
-/* Certificate for one straight piece of the wall search inside ONE profile segment (tables linear): from (x0, y0) at
- * height zrel0 above the segment's first node, along the direction (dx, dy, dz), path length D.  seg_ext/es and seg_cap/cs
- * are the segment's ext and cap at its first node and their slopes.  Returns 1 when no point of the piece can leave the
- * cell hexagon of centre K*zz or enter the capillary circle (margin 1e-6 of the cell size), 0 when that cannot be
- * shown, -1 when already the start point is within the margin. */
-PC_HD int pc_wall_piece_safe(const pc_params &Pm, double Kx, double Ky, int inside_stack, double x0, double y0, double zrel0,
-                             double dx, double dy, double dz, double D, double seg_ext, double es, double seg_cap, double cs)
+/* Largest certified fraction of one straight piece of the wall search.  In the plane of the cell (q_i, r_i) and relative to
+ * its centre the piece runs from ua to ub (the ray minus K times the chord of zh over the block); ha, hb are the inradius of
+ * the cell hexagon at both ends less every allowance (chord deviation, margin), rr the square of the radius the piece must
+ * stay outside of (negative: no capillary to avoid).  Returns t in [0, 1]: on [0, t] of the piece every hexagon test holds
+ * (|n.u| is convex along the piece and the bound linear, so both ends suffice) and the closest approach to the centre stays
+ * outside rr; 0 when already the start point cannot be certified.  A t < 1 is estimated in single precision and then
+ * VERIFIED in double precision, so the estimate decides nothing. */
+PC_HD double pc_wall_reach(double uax, double uay, double ubx, double uby, double ha, double hb, double rr)
 {
-	/* a certificate, not an outcome: products with 1/hexscale instead of the reference's quotients, and the closest approach
-	 * of the piece to the cell centre compared without its quotient (the margins are 1e-6 of the cell size, rounding 1e-16) */
-	const double ih = Pm.inv_hexscale;
-	const double zz0 = (es * zrel0 + seg_ext) * ih;
-	const double dzz = es * dz * ih;                          /* d zz / d path */
-	const double r00 = cs * zrel0 + seg_cap;
-	const double u0x = x0 - Kx*zz0, u0y = y0 - Ky*zz0;
-	const double vx = dx - Kx*dzz, vy = dy - Ky*dzz;
-	const double margin = 1.e-6 * zz0;
-	const double u1x = u0x + vx*D, u1y = u0y + vy*D;
-	const double h0 = PC_COSPI_6*zz0 - margin, h1 = PC_COSPI_6*(zz0 + dzz*D) - margin;
-	if (fabs(u0x) > h0 || fabs(0.5*u0x + PC_COSPI_6*u0y) > h0 || fabs(0.5*u0x - PC_COSPI_6*u0y) > h0) return -1;
-	if (fabs(u1x) > h1 || fabs(0.5*u1x + PC_COSPI_6*u1y) > h1 || fabs(0.5*u1x - PC_COSPI_6*u1y) > h1) return 0;
-	if (inside_stack) {
-		/* squared distance of the piece u0 + v t, t in [0, D], to the centre: at t = 0 when it moves away, at t = D when the
-		 * foot of the perpendicular lies beyond, else |u0|^2 - (u0.v)^2/|v|^2 -- compared with rmax^2 after multiplying by |v|^2 */
-		const double vv = vx*vx + vy*vy, uv = u0x*vx + u0y*vy, uu = u0x*u0x + u0y*u0y;
-		const double r1 = r00 + cs*dz*D;
-		const double rmax = ((r00 > r1) ? r00 : r1) + margin;
-		const double rr = rmax*rmax * (1. + 1.e-12);
-		int near;
-		if (!(uv < 0.)) near = uu < rr;                               /* moving away from the centre (or not moving) */
-		else if (-uv >= vv*D) near = (u1x*u1x + u1y*u1y) < rr;         /* still approaching at the end of the piece */
-		else near = (uu*vv - uv*uv) < rr*vv;
-		if (near) return 0;
+	const double a1 = uax, a2 = 0.5*uax + PC_COSPI_6*uay, a3 = 0.5*uax - PC_COSPI_6*uay;
+	if (!(fabs(a1) <= ha && fabs(a2) <= ha && fabs(a3) <= ha)) return 0.;
+	const double ex = ubx - uax, ey = uby - uay;
+	const double ee = ex*ex + ey*ey, ae = uax*ex + uay*ey, aa = uax*uax + uay*uay;
+	if (rr >= 0. && !(aa > rr)) return 0.;
+	const double b1 = ubx, b2 = 0.5*ubx + PC_COSPI_6*uby, b3 = 0.5*ubx - PC_COSPI_6*uby;
+	float t = 1.f;
+	if (fabs(b1) > hb) { const double num = ha - ((b1 < 0.) ? -a1 : a1); const float tk = (float)num / (float)(num + (fabs(b1) - hb)); if (tk < t) t = tk; }
+	if (fabs(b2) > hb) { const double num = ha - ((b2 < 0.) ? -a2 : a2); const float tk = (float)num / (float)(num + (fabs(b2) - hb)); if (tk < t) t = tk; }
+	if (fabs(b3) > hb) { const double num = ha - ((b3 < 0.) ? -a3 : a3); const float tk = (float)num / (float)(num + (fabs(b3) - hb)); if (tk < t) t = tk; }
+	if (rr >= 0. && ae < 0.) {
+		const double disc = ae*ae - ee*(aa - rr);
+		if (disc > 0.) { const float tc = (float)(-ae - sqrt(disc)) / (float)ee; if (tc < t) t = tc; }
 	}
-	return 1;
+	double td = (t >= 1.f) ? 1. : (double)t * (1. - 1./32768.);
+	for (int tries = 0; tries < 3; tries++) {
+		if (!(td > 0.)) break;
+		const double ux = uax + td*ex, uy = uay + td*ey, ht = ha + td*(hb - ha);
+		int ok = (fabs(ux) <= ht && fabs(0.5*ux + PC_COSPI_6*uy) <= ht && fabs(0.5*ux - PC_COSPI_6*uy) <= ht);
+		if (ok && rr >= 0. && ae < 0.) {
+			/* squared distance of u_a + e s, s in [0, td], to the centre: at s = td when the foot of the perpendicular lies
+			 * beyond, else |u_a|^2 - (u_a.e)^2/|e|^2 (compared after multiplying by |e|^2) */
+			if (-ae >= ee*td) ok = (ux*ux + uy*uy) > rr;
+			else ok = (aa*ee - ae*ae) > rr*ee;
+		}
+		if (ok) return td;
+		td = (td == 1.) ? 0.99 : 0.5*td;
+	}
+	return 0.;
 }
 
 /* one unit of the stepping loop (:1016-1064): either one certified block of steps, or one literal step with its tests */
@@ -450,140 +453,97 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 	 * never changes; the reference would loop forever): the reflection is reported as failed (launch returns -1). */
 	if (++W.units > (1 << 28)) { W.wt = -3; return after; }
 
-	/* ---- certified skipping.  Inside one profile segment the point relative to the centre of cell (q_i, r_i),
-	 * u = p - K*zz(z), moves on a straight line while the cell hexagon (inradius zz*sqrt(3)/2) and the capillary circle
-	 * (radius rad0) change linearly.  |n.u| - h is convex along such a piece, so the hexagon tests hold on it if they hold
-	 * at both ends; the circle test holds if the closest approach of the line to the centre stays outside the larger of
-	 * the two end radii (pc_wall_piece_safe, margin 1e-6 of the cell size, far above rounding).  None of the literal
-	 * steps that land on a safe piece can leave the loop, so only their effect on `dist` is carried out: a block runs to
-	 * the last step inside the segment, and the step that crosses into the next segment is taken along with it when the
-	 * two short pieces up to the node and from the node to the landing point are safe too -- then the next segment follows
-	 * in the same unit. */
-	if (!Pm.literal && W.cool == 0 && dz > 0.) {
+	/* ---- certified skipping.  Relative to the centre of cell (q_i, r_i) the ray is u(z) = p(z) - K*zh(z).  Inside one
+	 * profile segment zh is linear, and over a block of PC_L1 / PC_L2 segments it stays within md_L (tabulated, pc_marg4) of
+	 * the chord between the block's end nodes: u stays within |K| md_L of a straight piece, the cell's inradius within
+	 * cos30 md_L of the chord's, the capillary never wider than the block's largest radius.  pc_wall_reach gives the
+	 * fraction of such a piece on which no literal step can leave the loop (neither into another cell nor into the
+	 * capillary), with the allowances taken off and a margin of 1e-6 of the cell size, far above rounding; a piece that is
+	 * safe to its end is followed by the next one.  Up to the height zT reached this way only the count of steps per
+	 * segment -- exactly the literal arithmetic's dist = base + nst*step -- is carried out. */
+	if (!Pm.literal && W.cool == 0 && dz > 0. && T.z[z_id] <= W.pz && W.pz < T.z[z_id+1]) {
 		const int inside_stack = (fabs(W.q_i) <= ns && fabs(W.r_i) <= ns && fabs(-1.*W.q_i-W.r_i) <= ns);
 		const double Kx = (2.*W.q_i + W.r_i) * PC_COSPI_6, Ky = W.r_i * 1.5;
+		const double kab = fabs(Kx) + fabs(Ky);          /* >= |K| */
+		double zs = W.pz, xs = W.px, ys = W.py;          /* start of the next piece, in segment `is` (or at its first node) */
+		int is = z_id;
+		double zT = zs;
+		for (int piece = 0; piece < PC_WALL_PIECES && is < nmax; piece++) {
+			const pc_marg4 g = T.mg[is];
+			const double zA = T.z[is], zhA = T.zh[is], zh1 = T.zh[is+1];
+			const double zh_s = zhA + (zh1 - zhA)*((zs - zA)*T.idz[is]);
+			const double capA = T.cap[is];
+			const double r_s = capA + (T.cap[is+1] - capA)*((zs - zA)*T.idz[is]);      /* radius at the start of the piece */
+			/* the widest block whose allowances are small against the room the start point has to the cell edge and to the
+			 * capillary (a choice, not a certificate) */
+			const double usx = xs - Kx*zh_s, usy = ys - Ky*zh_s;
+			const double s1 = fabs(usx), s2 = fabs(0.5*usx + PC_COSPI_6*usy), s3 = fabs(0.5*usx - PC_COSPI_6*usy);
+			const double room_h = PC_COSPI_6*zh_s - ((s1 > s2) ? ((s1 > s3) ? s1 : s3) : ((s2 > s3) ? s2 : s3));
+			const double uu_s = usx*usx + usy*usy;
+			int lv = 0;
+			for (int l = 1; l <= 2; l++) {
+				if (is + ((l == 2) ? PC_L2 : PC_L1) > nmax) break;
+				const double al = 4.*((PC_COSPI_6 + kab)*(double)((l == 2) ? g.md2 : g.md1) + (double)((l == 2) ? T.dr[is].d2 : T.dr[is].d1));
+				if (!(al < room_h) || (inside_stack && !(uu_s > (r_s + al)*(r_s + al)))) break;
+				lv = l;
+			}
+			const int ib = is + ((lv == 2) ? PC_L2 : ((lv == 1) ? PC_L1 : 1));
+			const double md = (lv == 2) ? (double)g.md2 : ((lv == 1) ? (double)g.md1 : 0.);
+			const double zB = T.z[ib], zhB = T.zh[ib];
+			const double fs = (lv == 0) ? 0. : pc_div_fast(zs - zA, zB - zA);
+			const double zha = (lv == 0) ? zh_s : zhA + (zhB - zhA)*fs;    /* the chord at the start */
+			const double tB = (zB - zs)*ph.idzd;
+			const double xb = xs + tB*dx, yb = ys + tB*dy;
+			const double margin = 1.e-6 * zha;
+			const double dev = (PC_COSPI_6 + kab)*md*(1. + 1.e-6) + margin;
+			double rr = -1.;
+			if (inside_stack) {
+				/* the radius along the piece: never above the larger end value of its chord plus the chord deviation of cap */
+				const double capB = T.cap[ib];
+				const double rc = (lv == 0) ? r_s : capA + (capB - capA)*fs;
+				const double drd = (lv == 2) ? (double)T.dr[is].d2 : ((lv == 1) ? (double)T.dr[is].d1 : 0.);
+				const double reach = ((rc > capB) ? rc : capB) + drd + kab*md*(1. + 1.e-6) + margin*(1. + 1.e-3);
+				rr = reach*reach*(1. + 1.e-12);
+			}
+			const double t = pc_wall_reach(xs - Kx*zha, ys - Ky*zha, xb - Kx*zhB, yb - Ky*zhB,
+			                               PC_COSPI_6*zha - dev, PC_COSPI_6*zhB - dev, rr);
+			if (!(t > 0.)) break;
+			zT = zs + t*(zB - zs);
+			if (t < 1.) break;
+			zs = zB; xs = xb; ys = yb; is = ib;
+		}
 		int advanced = 0;
-		/* ---- blocks of PC_L2 / PC_L1 segments.  Over L segments zh stays within md_L (tabulated, pc_marg4) of the chord between
-		 * its two end nodes, so u = p - K*zh stays within |K| md_L of the straight line between its two end values taken with
-		 * the chord, and the cell's inradius within cos30 md_L of the chord's: the hexagon tests hold on the whole block if they
-		 * hold at both ends with (|K| + cos30) md_L taken off (|n.u| convex, the bound linear), and the capillary (never wider
-		 * than the block's largest radius, r2/2) is not met when the line's closest approach to the cell centre is farther than
-		 * r2/2 + |K| md_L.  Then no literal step that lands before the end of the block can leave the loop, and only the count
-		 * of steps per segment -- exactly the literal arithmetic's -- is carried out. */
-		if (T.z[z_id] <= W.pz && W.pz < T.z[z_id+1]) {
-			const double kab = fabs(Kx) + fabs(Ky);          /* >= |K| */
-			const pc_marg4 g = T.mg[z_id];
-			for (int lv = 2; lv >= 1 && !advanced; lv--) {
-				const int i1 = z_id + ((lv == 2) ? PC_L2 : PC_L1);
-				if (i1 > nmax-1) continue;
-				const double md = (double)((lv == 2) ? g.md2 : g.md1);
-				const double zA = T.z[z_id], zB = T.z[i1], zhA = T.zh[z_id], zhB = T.zh[i1];
-				const double zha = zhA + (zhB - zhA)*((W.pz - zA)/(zB - zA));      /* the chord at the current point */
-				const double tB = (zB - W.pz)*ph.idzd;
-				const double ubx = (W.px + tB*dx) - Kx*zhB, uby = (W.py + tB*dy) - Ky*zhB;
-				const double uax = W.px - Kx*zha, uay = W.py - Ky*zha;
-				const double margin = 1.e-6 * zha;
-				const double dev = (PC_COSPI_6 + kab)*md*(1. + 1.e-6) + margin;
-				const double ha = PC_COSPI_6*zha - dev, hb = PC_COSPI_6*zhB - dev;
-				if (fabs(uax) > ha || fabs(0.5*uax + PC_COSPI_6*uay) > ha || fabs(0.5*uax - PC_COSPI_6*uay) > ha) continue;
-				if (fabs(ubx) > hb || fabs(0.5*ubx + PC_COSPI_6*uby) > hb || fabs(0.5*ubx - PC_COSPI_6*uby) > hb) continue;
-				if (inside_stack) {
-					const double ex = ubx - uax, ey = uby - uay;
-					const double ee = ex*ex + ey*ey, ae = uax*ex + uay*ey, aa = uax*uax + uay*uay;
-					const double reach = 0.5*(double)g.r2 + kab*md*(1. + 1.e-6) + margin;
-					const double rr = reach*reach*(1. + 1.e-12);
-					int far;
-					if (!(ae < 0.)) far = aa > rr;
-					else if (-ae >= ee) far = (ubx*ubx + uby*uby) > rr;
-					else far = (aa*ee - ae*ae) > rr*ee;
-					if (!far) continue;
+		if (zT > W.pz) {
+			for (int guard = 0; guard < 4*PC_L2*PC_WALL_PIECES; guard++) {
+				const double stp = T.stp[z_id];
+				const double z1 = T.z[z_id+1];
+				const double zlim = (z1 < zT) ? z1 : zT;
+				/* candidate count of steps that land before zlim, checked against the positions the literal arithmetic produces */
+				const double room = (zlim - W.pz)*ph.idzd*T.istp[z_id];
+				int m = (room > 1.e6) ? 1000000 : (int)room;
+				if (m < 0) m = 0;
+				const long long n0 = (z_id != W.seg_step) ? 0 : W.nst;
+				const double b0 = (z_id != W.seg_step) ? W.dist : W.base;
+				if (m >= 1 && !(Pz + (b0 + (double)(n0 + m)*stp)*dz < zlim)) m--;
+				if (m >= 1 && !(Pz + (b0 + (double)(n0 + m)*stp)*dz < zlim)) m--;
+				if (m >= 1 && !(Pz + (b0 + (double)(n0 + m)*stp)*dz < zlim)) m = 0;
+				/* the step over the node, when the certified stretch goes on behind it */
+				int steps = m, on = 0;
+				if (z1 < zT && Pz + (b0 + (double)(n0 + m + 1)*stp)*dz < zT) { steps = m + 1; on = 1; }
+				if (steps > 0) {
+					if (z_id != W.seg_step) { W.seg_step = z_id; W.step = stp; W.base = W.dist; W.nst = 0; }
+					W.nst += steps;
+					W.dist = W.base + (double)W.nst*W.step;
+					W.px = Px + W.dist*dx;
+					W.py = Py + W.dist*dy;
+					W.pz = Pz + W.dist*dz;
+					z_id = pc_node_follow(T, nmax, z_id, W.pz);
+					advanced = 1;
 				}
-				/* certified up to zB: per segment the steps that land inside it and the one that crosses its end */
-				for (int guard = 0; z_id < i1 && guard < 4*PC_L2; guard++) {
-					const double stp = T.cap[z_id]/10.;
-					const double z1 = T.z[z_id+1];
-					const double room = (z1 - W.pz)*ph.idzd*(10./T.cap[z_id]);
-					int m = (room > 1.e6) ? 1000000 : (int)room;
-					if (m < 0) m = 0;
-					const long long n0 = (z_id != W.seg_step) ? 0 : W.nst;
-					const double b0 = (z_id != W.seg_step) ? W.dist : W.base;
-					if (m >= 1 && !(Pz + (b0 + (double)(n0 + m)*stp)*dz < z1)) m--;
-					if (m >= 1 && !(Pz + (b0 + (double)(n0 + m)*stp)*dz < z1)) m--;
-					int steps = m + 1, last = 0;
-					if (!(Pz + (b0 + (double)(n0 + steps)*stp)*dz < zB)) { steps = m; last = 1; }
-					if (steps > 0) {
-						if (z_id != W.seg_step) { W.seg_step = z_id; W.step = stp; W.base = W.dist; W.nst = 0; }
-						W.nst += steps;
-						W.dist = W.base + (double)W.nst*W.step;
-						W.px = Px + W.dist*dx;
-						W.py = Py + W.dist*dy;
-						W.pz = Pz + W.dist*dz;
-						z_id = pc_node_follow(T, nmax, z_id, W.pz);
-						advanced = 1;
-					}
-					if (last || steps == 0) break;
-				}
-				W.z_id = z_id;
+				if (!on) break;
 			}
-			if (advanced) { PC_LSTAT(9); return PC_LS_WALL_STEP; }
 		}
-		for (int hop = 0; hop < PC_WALL_HOPS; hop++) {
-			if (!(T.z[z_id] <= W.pz && W.pz < T.z[z_id+1])) break;
-			const double stp = T.cap[z_id]/10.;
-			/* candidate block length: checked below against the positions the literal arithmetic produces, so a product with
-			 * reciprocals does (1/dz is the ray's) */
-			const double room = (T.z[z_id+1] - W.pz)*ph.idzd*(10./T.cap[z_id]);
-			/* the block may run up to the last step that still lands inside this segment: the candidate count from the
-			 * division is checked against the position the literal arithmetic would produce there */
-			int m = (room > 1.e6) ? 1000000 : (int)room;
-			const long long n0 = (z_id != W.seg_step) ? 0 : W.nst;
-			const double b0 = (z_id != W.seg_step) ? W.dist : W.base;
-			if (m >= 1 && !(Pz + (b0 + (double)(n0 + m)*stp)*dz < T.z[z_id+1])) m--;
-			if (m >= 1 && !(Pz + (b0 + (double)(n0 + m)*stp)*dz < T.z[z_id+1])) m--;
-			const int m_full = m;
-			/* slopes of the certificate: with the tabulated 1/dz */
-			const double es = (T.ext[z_id+1] - T.ext[z_id])*T.idz[z_id], cs = (T.cap[z_id+1] - T.cap[z_id])*T.idz[z_id];
-			int ok = (m == 0);                 /* nothing left inside this segment: only the crossing step remains */
-			for (; m >= 2 && !ok; m = (m == m_full && hop > 0) ? 0 : (m >> 2)) {
-				const double D = (double)m * stp * (1. + 1.e-9);
-				const int r = pc_wall_piece_safe(Pm, Kx, Ky, inside_stack, W.px, W.py, W.pz - T.z[z_id], dx, dy, dz, D, T.ext[z_id], es, T.cap[z_id], cs);
-				if (r < 0) break;                /* the start point itself is within the margin */
-				if (r > 0) { ok = 1; break; }
-			}
-			if (!ok || (m < 2 && m != 0)) break;
-			if (m > 0) {
-				if (z_id != W.seg_step) { W.seg_step = z_id; W.step = stp; W.base = W.dist; W.nst = 0; }
-				W.nst += m;
-				W.dist = W.base + (double)W.nst*W.step;
-				W.px = Px + W.dist*dx;
-				W.py = Py + W.dist*dy;
-				W.pz = Pz + W.dist*dz;
-				advanced = 1;
-			}
-			if (m != m_full || z_id + 1 >= nmax) break;       /* a shortened block, or the last segment: no crossing here */
-			/* ---- the crossing step: from the last point inside the segment over the node to the landing point */
-			const long long n1 = (z_id != W.seg_step) ? 0 : W.nst;
-			const double b1 = (z_id != W.seg_step) ? W.dist : W.base;
-			const double qd = b1 + (double)(n1 + 1)*stp;
-			const double qz = Pz + qd*dz;                                          /* z of the landing point of the crossing step */
-			if (!(T.z[z_id+1] <= qz && qz < T.z[z_id+2])) break;
-			const double tB = (T.z[z_id+1] - W.pz)*ph.idzd * (1. + 2.e-9);       /* path length to the node (certificate: product with 1/dz) */
-			if (pc_wall_piece_safe(Pm, Kx, Ky, inside_stack, W.px, W.py, W.pz - T.z[z_id], dx, dy, dz, tB, T.ext[z_id], es, T.cap[z_id], cs) <= 0) break;
-			const double esn = (T.ext[z_id+2] - T.ext[z_id+1])*T.idz[z_id+1], csn = (T.cap[z_id+2] - T.cap[z_id+1])*T.idz[z_id+1];
-			const double bx = Px + (W.dist + tB)*dx, by = Py + (W.dist + tB)*dy;     /* the ray at (just past) the node */
-			const double tQ = (qd - W.dist - tB);
-			if (tQ > 0. && pc_wall_piece_safe(Pm, Kx, Ky, inside_stack, bx, by, 0., dx, dy, dz, tQ * (1. + 1.e-9) + 1.e-12*stp, T.ext[z_id+1], esn, T.cap[z_id+1], csn) <= 0) break;
-			if (z_id != W.seg_step) { W.seg_step = z_id; W.step = stp; W.base = W.dist; W.nst = 0; }
-			W.nst += 1;
-			W.dist = W.base + (double)W.nst*W.step;
-			W.px = Px + W.dist*dx;
-			W.py = Py + W.dist*dy;
-			W.pz = Pz + W.dist*dz;
-			z_id = pc_node_follow(T, nmax, z_id, W.pz);
-			W.z_id = z_id;
-			advanced = 1;
-		}
-		if (advanced) { PC_LSTAT(0); return PC_LS_WALL_STEP; }
+		if (advanced) { W.z_id = z_id; PC_LSTAT(0); return PC_LS_WALL_STEP; }
 		W.cool = 1;      /* a cell edge or the capillary is within a step or two: one literal step, then try again */
 	}
 	if (W.cool > 0) W.cool--;

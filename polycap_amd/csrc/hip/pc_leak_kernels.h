@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(PC_LEAK_BLOCK, PC_LEAK_MIN_WAVES)
 pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 {
 	constexpr bool EXPLICIT = (MODE == PC_MODE_EXPLICIT);
-	__shared__ double lds[7*PITCH];
+	constexpr int NT = (PITCH <= 1024) ? 9 : 7;      /* the step tables of the wall search fit next to the others up to 1024 points */
+	__shared__ double lds[NT*PITCH];
 	__shared__ pc_marg4 ldsg[PITCH];
 	const int npts = a.pm.nmax + 1;
 	for (int k = threadIdx.x; k < npts; k += blockDim.x) {
@@ -53,12 +54,14 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 		lds[4*PITCH + k] = a.g_hexd[k];
 		lds[5*PITCH + k] = a.g_idz[k];
 		lds[6*PITCH + k] = a.g_ext[k];
+		if (NT == 9) { lds[7*PITCH + k] = a.g_stp[k]; lds[8*PITCH + k] = a.g_istp[k]; }
 		ldsg[k] = a.g_mg[k];
 	}
 	__syncthreads();
 	pc_tables T;
 	T.z = lds; T.cap = lds + PITCH; T.zh = lds + 2*PITCH; T.cap2 = lds + 3*PITCH; T.hexd = lds + 4*PITCH; T.idz = lds + 5*PITCH;
 	T.ext = lds + 6*PITCH;
+	T.stp = (NT == 9) ? lds + 7*PITCH : a.g_stp; T.istp = (NT == 9) ? lds + 8*PITCH : a.g_istp;
 	T.mg = ldsg;
 	const pc_params &Pm = a.pm;
 	const int ne = Pm.n_energies;

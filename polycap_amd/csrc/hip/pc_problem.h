@@ -26,7 +26,8 @@
 #define PC_R0     2.8179403227e-13
 
 struct pc_host_tables {
-	std::vector<double> z, cap, zh, cap2, hexd, idz, ext;
+	std::vector<double> z, cap, zh, cap2, hexd, idz, ext, stp, istp;
+	std::vector<pc_drdev> dr;                 /* chord deviations of cap (leak path) */
 	std::vector<float> mb1, md1, mb2, md2;   /* block-certificate tables for strides PC_L1, PC_L2 */
 	std::vector<pc_marg4> mg;                /* the same, packed per node (what pc_march_ok reads) */
 	std::vector<pc_energy_const> ec;
@@ -69,12 +70,14 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 	t.z.assign(p->z, p->z + n);
 	t.cap.assign(p->cap, p->cap + n);
 	t.ext.assign(p->ext, p->ext + n);
-	t.zh.resize(n); t.cap2.resize(n); t.hexd.resize(n); t.idz.assign(n, 0.);
+	t.zh.resize(n); t.cap2.resize(n); t.hexd.resize(n); t.idz.assign(n, 0.); t.stp.resize(n); t.istp.resize(n);
 	double dr2max = 0., capmin = HUGE_VAL, capmax = 0., extmax = 0., ratio = 0.;
 	for (int i = 0; i < n; i++) {
 		double e = p->ext[i], c = p->cap[i];
 		t.zh[i] = e / pm.hexscale;
 		t.cap2[i] = c*c;
+		t.stp[i] = c/10.;
+		t.istp[i] = 10./c;
 		t.hexd[i] = (e > 0.) ? std::sqrt(e*e - (e/2.)*(e/2.)) : 0.;
 		if (i + 1 < n) {
 			t.idz[i] = 1.0 / (p->z[i+1] - p->z[i]);
@@ -100,6 +103,7 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 		std::vector<float> &md = (lvl == 1) ? t.md1 : t.md2;
 		mb.assign(n, HUGE_VALF);
 		md.assign(n, HUGE_VALF);
+		if (lvl == 1) t.dr.assign(n, pc_drdev{HUGE_VALF, HUGE_VALF});
 		for (int i = 0; i + L < n; i++) {
 			const double za = p->z[i], zb = p->z[i+L], span = zb - za;
 			double dzh = 0., dr = 0.;
@@ -122,6 +126,9 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 			if ((double)fd < dzh) fd = std::nextafter(fd, HUGE_VALF);
 			mb[i] = fb;
 			md[i] = fd;
+			float fr = (float)dr;
+			if ((double)fr < dr) fr = std::nextafter(fr, HUGE_VALF);
+			if (lvl == 1) t.dr[i].d1 = fr; else t.dr[i].d2 = fr;
 		}
 	}
 	/* packed per start node (pc_marg4): margin bases inflated, rounded up and cut to their upper 16 bits (rounded up again:

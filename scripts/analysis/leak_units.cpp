@@ -24,7 +24,7 @@ extern "C" int leak_units(const pc_hip_problem *p, uint64_t seed, int64_t slot0,
 	if (pc_build_tables(p, t, err)) return 1;
 	pc_tables T;
 	T.z = t.z.data(); T.cap = t.cap.data(); T.zh = t.zh.data(); T.cap2 = t.cap2.data(); T.hexd = t.hexd.data(); T.idz = t.idz.data(); T.ext = t.ext.data();
-	T.mg = t.mg.data();
+	T.mg = t.mg.data(); T.stp = t.stp.data(); T.istp = t.istp.data(); T.dr = t.dr.data();
 	const pc_params &Pm = t.pm;
 	const int ne = (int)p->n_energies;
 #pragma omp parallel

@@ -38,7 +38,7 @@ print("share of the total in the heaviest 1 %% of the slots: %.2f; the heaviest 
 L.leak_stats.restype = C.POINTER(C.c_longlong * 16)
 st = list(L.leak_stats().contents)
 names = ["wall step: certified block", "wall step: literal step", "cell changes (probes begun)", "probe: 1-segment skip", "probe: %d-segment skip",
-         "probe: %d-segment skip", "probe: segment visited, miss", "probe: segment visited, hit", "wall searches begun", "wall step: block of 5 or 25 segments", "outer hexagon searched", "outer hexagon: nodes tested", "outer hexagon: blocks skipped"]
+         "probe: %d-segment skip", "probe: segment visited, miss", "probe: segment visited, hit", "wall searches begun", "-", "outer hexagon searched", "outer hexagon: nodes tested", "outer hexagon: blocks skipped"]
 print("units of the wall search by outcome, per wall search:")
 for k, nm in enumerate(names):
     print("  %-36s %10d  %7.2f" % (nm % ((5, 25)[k - 4],) if "%d" in nm else nm, st[k], st[k] / max(1, st[8])))

@@ -24,7 +24,7 @@ summary = {}
 meta = {}
 for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_%s_pmc*" % tag))):
     for f in sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:     # the newest pass only
-        rows = [r for r in csv.DictReader(open(f)) if "pc_trace" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if "pc_trace" in r["Kernel_Name"] or "pc_leak" in r["Kernel_Name"]]
         # the trace kernel of the timed steps: the one with the most dispatches (a context's first big run is preceded by a
         # small probe launch of the default kernel, which is not what is profiled)
         names = collections.Counter(r["Kernel_Name"] for r in rows)

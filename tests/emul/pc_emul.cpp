@@ -35,6 +35,7 @@ int setup(const pc_hip_problem *p, int literal, Emul &E)
 	E.T.z = E.t.z.data(); E.T.cap = E.t.cap.data(); E.T.zh = E.t.zh.data();
 	E.T.cap2 = E.t.cap2.data(); E.T.hexd = E.t.hexd.data(); E.T.idz = E.t.idz.data(); E.T.ext = E.t.ext.data();
 	E.T.mg = E.t.mg.data();
+	E.T.stp = E.t.stp.data(); E.T.istp = E.t.istp.data(); E.T.dr = E.t.dr.data();
 	return 0;
 }
 
