@@ -21,6 +21,9 @@
 #ifndef PC_PRODUCER_KERNEL_H
 #define PC_PRODUCER_KERNEL_H
 
+#ifndef PC3_ROUTE_BND
+#define PC3_ROUTE_BND 1       /* photons of boundary capillaries are handed to the last tracing wave (see producer_step) */
+#endif
 #ifndef PC3_BLOCK
 #define PC3_BLOCK 1024         /* one workgroup per CU: 1 launching + 15 tracing waves, the tables once in LDS */
 #endif
@@ -325,16 +328,25 @@ pc_trace_producer_kernel(pc_kargs a)
 				const int nfail = __popcll(__ballot(f_fail));
 				if (nfail > 0 && lane == 0) atomicSub(&ctl.outstanding, (unsigned int)nfail);
 			}
-			/* entered photons into the rings: the r-th of them goes to the ring whose share of the free places holds r */
-			const unsigned long long mI = __ballot(entered);
-			const int r = __popcll(mI & below);
+			/* entered photons into the rings.  Photons of boundary capillaries (about one in a hundred on a 200 000-capillary
+			 * optic) go to the LAST ring while it has room: the hexagon tests they need in every march step and segment visit
+			 * are then executed by one tracing wave instead of by every wave that happens to hold one.  The r-th of the others
+			 * goes to the ring whose share of the remaining free places holds r. */
+			const int f_last = __shfl(myfree, PC3_CONSUMERS - 1, PC_WAVE);
+			const unsigned long long mB = __ballot(entered && PC3_ROUTE_BND && np.bnd);
+			const int nb_last = min(__popcll(mB), f_last);
+			const int rb = __popcll(mB & below);
+			const int to_last = entered && PC3_ROUTE_BND && np.bnd && rb < nb_last;
+			const unsigned long long mOth = __ballot(entered && !to_last);
+			const int r = __popcll(mOth & below);
 			int my_c = -1, my_pos = 0;
 #pragma unroll
 			for (int c = 0; c < PC3_CONSUMERS; c++) {
-				const int hi = __shfl(cum, c, PC_WAVE);
+				const int hi = __shfl(cum, c, PC_WAVE) - ((c == PC3_CONSUMERS - 1) ? nb_last : 0);
 				const int lo = (c == 0) ? 0 : __shfl(cum, c - 1, PC_WAVE);
-				if (entered && my_c < 0 && r >= lo && r < hi) { my_c = c; my_pos = r - lo; }
+				if (entered && !to_last && my_c < 0 && r >= lo && r < hi) { my_c = c; my_pos = r - lo + ((c == PC3_CONSUMERS - 1) ? nb_last : 0); }
 			}
+			if (to_last) { my_c = PC3_CONSUMERS - 1; my_pos = rb; }
 			if (entered && my_c >= 0) {
 				const unsigned int e = (ctl.q_tail[my_c] + (unsigned)my_pos) % PC3_CAP;
 				double *q = l_ring + (size_t)my_c*(PC3_FIELDS*PC3_CAP) + e;
@@ -349,11 +361,13 @@ pc_trace_producer_kernel(pc_kargs a)
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			{
 				/* publish: ring c received min(n_entered, cum[c]) - min(n_entered, cum[c-1]) photons */
-				const int ne_tot = __popcll(mI);
+				const int ne_tot = __popcll(mOth);
 				const int prev = __shfl_up(cum, 1, PC_WAVE);
 				if (lane < PC3_CONSUMERS) {
+					const int last = (lane == PC3_CONSUMERS - 1);
 					const int lo = (lane == 0) ? 0 : prev;
-					const int n_c = ((ne_tot < cum) ? ne_tot : cum) - ((ne_tot < lo) ? ne_tot : lo);
+					const int hi = cum - (last ? nb_last : 0);
+					const int n_c = ((ne_tot < hi) ? ne_tot : hi) - ((ne_tot < lo) ? ne_tot : lo) + (last ? nb_last : 0);
 					if (n_c > 0) pc3_store(&ctl.q_tail[lane], ctl.q_tail[lane] + (unsigned)n_c);
 				}
 			}
