@@ -393,7 +393,14 @@ PC_HD int pc_wall_begin(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 }
 
 #ifndef PC_PROBE_BLOCKS
-#define PC_PROBE_BLOCKS 4  /* certified blocks of segments one unit of the capillary probe may skip */
+#define PC_PROBE_BLOCKS 16 /* certified blocks of segments the capillary probe may skip between two segment visits; measured on MI355X
+                            * (scripts/ab_leak.sh, mean life of a wave for 262144 slots): 1 -> 155 ms, 2 -> 147, 4 -> 138, 8 -> 130, 16 -> 127, 64 -> 127 */
+#endif
+#ifndef PC_PROBE_VISITS
+#define PC_PROBE_VISITS 1  /* segment visits (each preceded by its skipped blocks) one unit of the capillary probe may make: 1, 4, 16 measure the same */
+#endif
+#ifndef PC_WALL_SEGS
+#define PC_WALL_SEGS 300      /* profile segments one unit of the wall search may step through (the rest of a certified stretch waits for the next unit) */
 #endif
 #ifndef PC_WALL_PIECES
 #define PC_WALL_PIECES 3   /* straight pieces (blocks of 1, PC_L1 or PC_L2 segments) one unit of the wall search may certify */
@@ -514,7 +521,7 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 		}
 		int advanced = 0;
 		if (zT > W.pz) {
-			for (int guard = 0; guard < 4*PC_L2*PC_WALL_PIECES; guard++) {
+			for (int guard = 0; guard < PC_WALL_SEGS; guard++) {
 				const double stp = T.stp[z_id];
 				const double z1 = T.z[z_id+1];
 				const double zlim = (z1 < zT) ? z1 : zT;
@@ -613,7 +620,8 @@ PC_HD int pc_wall_probe(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 	 * and the radius never exceeds R_blk (the largest of the block, pc_marg4::r2 / 2), so when the chord's closest approach to
 	 * the axis is farther than R_blk + kn*md_L (+ margin) the ray is outside the capillary on all L segments: the reference's
 	 * quadratic (src/polycap-capil.c:119-171) has no root inside any of them and every one of the L visits is a miss.  A unit
-	 * takes up to PC_PROBE_BLOCKS such blocks. */
+	 * skips up to PC_PROBE_BLOCKS such blocks, visits the segment that could not be skipped, and goes on PC_PROBE_VISITS times. */
+	for (int visit = 0; visit < PC_PROBE_VISITS; visit++) {
 	int skipped = 0;
 	for (int blk = 0; blk < (Pm.literal ? 0 : PC_PROBE_BLOCKS); blk++) {
 		skipped = 0;
@@ -662,6 +670,8 @@ PC_HD int pc_wall_probe(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 		W.iesc = pc_segment(T, probe, W.z_id, p0x, p0y, W.hx, W.hy, W.hz, nx, ny, nz);
 		PC_LSTAT(W.iesc == 1 ? 7 : 6);
 		W.z_id++;
+	}
+	if (!(W.iesc != 1 && W.z_id < nmax-1)) break;          /* found the wall, or the end of the capillary */
 	}
 	if (W.iesc != 1 && W.z_id < nmax-1)
 		return PC_LS_WALL_PROBE;

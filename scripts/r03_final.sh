@@ -14,4 +14,6 @@ bash scripts/profile_r03.sh ne291 python3 scripts/side_workload.py sweep_291 > g
 bash scripts/profile_r03.sh ellip291 python3 scripts/side_workload.py ellip_291 > gpurun_out/final_prof_ellip291.log 2>&1
 timeout -k 10 300 python scripts/optconst_selfcheck.py --out gpurun_out/optconst_selfcheck.json > /dev/null 2> gpurun_out/optconst_selfcheck.err
 timeout -k 10 300 python scripts/bench_leak.py 16384,262144 > gpurun_out/leak_bench_r03.txt 2>&1
+POLYCAP_LEAK_TIMING=1 timeout -k 10 120 python scripts/leak_one.py 262144 1 > gpurun_out/leak_timing_r03.txt 2>&1
+bash scripts/profile_leak.sh leak > gpurun_out/final_prof_leak.log 2>&1
 tail -c 600 gpurun_out/bench_headline.json
