@@ -135,7 +135,7 @@ PC_HD int pc_outer_intersect(const pc_tables &T, const pc_params &Pm, double cx,
 	if (dz == 0.) return 0;
 	double bx = -1.*dx, by = -1.*dy, bz = -1.*dz;
 	pc_norm3(bx, by, bz);
-	int z_id = pc_node_find(T, nmax, cz);
+	int z_id = (nmax >= 1 && cz >= T.z[nmax-1]) ? nmax-1 : pc_node_find(T, nmax, cz);       /* called with the exit plane's z */
 	double cur_ext = (T.ext[z_id+1]-T.ext[z_id])/(T.z[z_id+1]-T.z[z_id]) * (cz - T.z[z_id]) + T.ext[z_id];
 	/* polycap_photon_within_pc_boundary: 1 inside, 0 outside, -1 for a non-positive radius */
 	const int here = (cur_ext <= 0.) ? -1 : (pc_outside_hex(cur_ext, cx, cy) ? 0 : 1);
@@ -360,7 +360,8 @@ PC_HD void pc_wall_to_exit(const pc_tables &T, const pc_params &Pm, pc_leak_lane
 }
 
 /* :918-971.  Returns the next state: WALL_STEP / WALL_PROBE, or `after` with W.wt <= 0 when there is nothing to trace */
-PC_HD int pc_wall_begin(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L, int after)
+/* `hint`: a node index near ph.Pz (the segment of the reflection) or -1 */
+PC_HD int pc_wall_begin(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L, int after, int hint = -1)
 {
 	pc_wall &W = L.w;
 	const pc_photon<0> &ph = L.ph;
@@ -369,7 +370,7 @@ PC_HD int pc_wall_begin(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 	W.d_travel = 0.; W.q_out = 0.; W.r_out = 0.; W.q_new = 0.; W.r_new = 0.;
 	W.wt = -2;
 	if (ph.Pz >= T.z[nmax]) return after;
-	int z_id = pc_node_find(T, nmax, ph.Pz);
+	int z_id = (hint >= 0 && hint < nmax) ? pc_node_follow(T, nmax, hint, ph.Pz) : pc_node_find(T, nmax, ph.Pz);     /* the same index either way */
 	double cur_ext;
 	if (T.z[z_id] != ph.Pz)
 		cur_ext = ((T.ext[z_id+1] - T.ext[z_id])/(T.z[z_id+1] - T.z[z_id])) * (ph.Pz - T.z[z_id]) + T.ext[z_id];
@@ -746,7 +747,7 @@ PC_HD void pc_leak_unit_other(const pc_tables &T, const pc_params &Pm, pc_leak_l
 		/* src/polycap-capil.c:596-619 */
 		L.geom_ok = pc_reflect_geom(ph, L.h.nx, L.h.ny, L.h.nz, L.g);     /* -1: alfa < 0 */
 		L.w.wt = 0;
-		L.st = (L.geom_ok >= 0) ? pc_wall_begin(T, Pm, L, PC_LS_REFLECT_END) : PC_LS_REFLECT_END;
+		L.st = (L.geom_ok >= 0) ? pc_wall_begin(T, Pm, L, PC_LS_REFLECT_END, L.h.ix) : PC_LS_REFLECT_END;
 		break;
 	}
 	case PC_LS_REFLECT_END: {
