@@ -23,6 +23,7 @@ Extra legs, rank 0 at N = 1 only, after the timed region (each bounded to second
                       (SURVEY 8d's wall = kernel + reduce + result copy-back; never `value`)
   sweep_291           BASELINE C3's kernel: xos1 on the deck's 291-energy grid, histogram only
   ellip_l9_rough      BASELINE C5's deck: ellip_l9.inp with sig_rough = 5 Angstrom, 1 and 291 energies
+  leak_262144         leak_calc=true: the reference's test optic, 10 keV, 262144 exit photons
   parity_fixture      the metric's parity half at the north-star N: the 128 committed oracle runs (tests/golden/
                       oracle_totals_xos1_10keV.json, 2.4e8 started photons) retraced on the device on identical seeds
   cpu_baseline        the CPU oracle (reference algorithm, OpenMP) on a bounded sample of the headline workload
@@ -228,6 +229,7 @@ def main():
             out["ellip_l9_rough"] = {"n_energies_1": side_workload("ellip_l9", [10.0], 5.0, 4_000_000, dev_index),
                                      "n_energies_291": side_workload("ellip_l9", None, 5.0, 500_000, dev_index,
                                                                      "profiles/r03/ellip291_pmc_summary.json")}
+            out["leak_262144"] = leak_workload(262_144, dev_index)
         if world == 1 and not args.no_extras:
             out["parity_fixture"] = parity_fixture(prob, dev_index)
         if not args.no_cpu_baseline and world == 1:
@@ -297,6 +299,28 @@ def side_workload(deck_name, energies, sig_rough, n_slots, dev_index, pmc_file=N
         except Exception:
             out["valu_issue"] = None
     return out
+
+
+def leak_workload(n_slots, dev_index):
+    """SURVEY 8(f) rank 1, leak_calc=true: the reference's ellipsoidal test optic (tests/leaks.c), uniform illumination, 10 keV,
+    one warm-up run + one timed run; kernel time by HIP events, wall = with the events fetched and put into the reference's list
+    order on the host."""
+    import polycap_amd
+    from polycap_amd import capi
+    from polycap_amd.decks import optical_constants
+    prof = capi.Profile(capi.Profile.ELLIPSOIDAL, 9., 0.2065, 0.0585, 0.00035, 9.9153e-5, 1000., 0.5)
+    a, s, _ = optical_constants([8, 14], [0.53, 0.47], 2.23, [10.0])
+    prob = polycap_amd.Problem(prof.get_z(), prof.get_cap(), prof.get_ext(), 0.0, 200000, 2.23, [10.0], a, s,
+                               2000.0, 0.2065, 0.2065, -1.0, 0.0, 0.0, 0.0, 0.5)
+    with polycap_amd.TraceContext(prob, dev_index) as c:
+        c.transmission(1, 0, 4096, leak_calc=True)
+        t0 = time.perf_counter()
+        r = c.transmission(20000, 0, n_slots, leak_calc=True)
+        dt = time.perf_counter() - t0
+    return {"workload": "leak_calc=true, ellipsoidal test optic of the reference's tests/leaks.c, 10 keV, %d exit photons" % n_slots,
+            "started_photons_per_s": r["i_start"] / (r["kernel_ms"] * 1e-3), "kernel_ms": r["kernel_ms"], "wall_ms": dt * 1e3,
+            "n_started": r["i_start"], "n_exit": r["i_exit"], "extleak_events": len(r["ext"]), "intleak_events": len(r["int"]),
+            "kernel": "pc_leak_kernel<0, 1024>"}
 
 
 def wall_incl_copyback(deck, n_photons, started_per_exit):

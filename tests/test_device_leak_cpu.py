@@ -57,9 +57,12 @@ def test_reference_known_answers(oracle, optic, leaks):
 
 
 def test_certified_skipping_is_bit_identical_to_literal_stepping(oracle, optic, leaks):
-    """The march certificates and the block skipping of the wall search must not change one bit of any result."""
+    """The march certificates and the certified skipping of the leak path -- wall search by reach, blocks of the capillary probe,
+    blocks of the outer-hexagon scan -- must not change one bit of any result or event record."""
     from tests.emul import pyemul
-    for energies, src, n in (([10.0, 40.0], DIVERGENT, 120), ([10.0], (2000., 0.2065, 0.2065, -1., 0., 0., 0., 0.5), 40)):
+    # (scripts/analysis/leak_literal_check.py runs the same comparison on thousands of photons per source)
+    for energies, src, n in (([10.0, 40.0], DIVERGENT, 300), ([10.0], (2000., 0.2065, 0.2065, -1., 0., 0., 0., 0.5), 300),
+                             ([40.0], (5., 0.15, 0.15, 0.04, 0.04, 0.02, 0.01, 0.5), 300)):
         cs = [constants(leaks, e) for e in energies]
         prob = problem(optic, energies, [a for a, _ in cs], [s for _, s in cs], source=src)
         ph = oracle.sample_photons(optic, oracle.make_source(*src), 4242, np.arange(n))
@@ -67,7 +70,7 @@ def test_certified_skipping_is_bit_identical_to_literal_stepping(oracle, optic, 
         lit = pyemul.launch_leak(prob, ph[:, 0:3], ph[:, 3:6], ph[:, 6:9], literal=True)
         for k in fast:
             assert np.array_equal(fast[k], lit[k], equal_nan=True), k
-        assert fast["records"].shape[0] > 20
+        assert fast["records"].shape[0] > 100
 
 
 def test_device_code_vs_oracle(oracle, optic, leaks):
