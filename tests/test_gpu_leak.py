@@ -168,6 +168,43 @@ def test_driver_with_leaks_vs_oracle(pa, oracle, optic, leaks):
         assert np.array_equal(np.concatenate([r["local"][kind] for r in ranks]), g[kind])
 
 
+def test_driver_with_leaks_is_event_for_event_the_host_compile(pa, oracle, optic, leaks):
+    """The source driver with leak_calc=true on the workload of the leak bench (uniform illumination, 10 keV), 3000 slots = 7700
+    launches: counters, the exit weight of every slot and every leak event (attempt by attempt, in list order inside an attempt)
+    equal the host compile of the same headers running the slots one
+    after the other -- geometry bit for bit, leak weights to 1e-12 (the device's exp is not glibc's).  Covers the certified
+    wall search, probe and outer-hexagon scan of the kernel against the sequential loop at a size where every branch occurs."""
+    from tests.emul import pyemul
+    amu, scatf = constants(leaks, 10)
+    src = (2000., 0.2065, 0.2065, -1., 0., 0., 0., 0.5)
+    prob = problem(pa, optic, [10.0], [amu], [scatf], source=src)
+    n = 3000
+    with pa.TraceContext(prob) as ctx:
+        g = ctx.transmission(20000, 0, n, keep_images=True, leak_calc=True)
+        gw = ctx.images()["exit_weights"]
+    e = pyemul.transmission_leak(prob, 20000, 0, n)
+    assert not e["stack_overflow"]
+    assert np.array_equal(np.asarray(g["counters"][:4], dtype=np.int64), e["counters"])
+    assert np.array_equal(np.asarray(gw).reshape(n, -1), e["exit_weights"])
+    rec = e["records"]
+    void = {(r[0], r[1]) for r in rec if r[3] < 0}
+    rec = rec[np.array([(r[0], r[1]) not in void and r[3] >= 0 for r in rec], dtype=bool)]
+    rec = rec[np.lexsort((rec[:, 2], rec[:, 1], rec[:, 0]))]                          # slot, attempt, seq
+    n_events = 0
+    for kind, got in ((0, g["ext"]), (1, g["int"])):
+        exp = rec[rec[:, 3] == kind]
+        assert got.shape[0] == exp.shape[0]
+        assert np.all(np.diff(got[:, 0]) >= 0)                                          # slot-major
+        # the kernel's lists hold a slot's transmitted attempt first (which attempt that was is not part of the emulation's
+        # output when it left no event): compared attempt by attempt, inside an attempt in list order
+        got = got[np.lexsort((got[:, 1], got[:, 0]))]                                   # stable: keeps the order inside an attempt
+        assert np.array_equal(got[:, 0:2], exp[:, 0:2])                                 # slot, attempt
+        assert np.array_equal(got[:, 2:12], exp[:, 4:14])                               # coords, direction, elecv, n_refl
+        assert np.allclose(got[:, 12:], exp[:, 14:], rtol=1e-12, atol=0.)
+        n_events += got.shape[0]
+    assert n_events > 20000
+
+
 @pytest.mark.parametrize("binding", ["ctypes", "cython"])
 def test_public_api_with_leaks(pa, leaks, known, binding, monkeypatch):
     """The reference's Python test of the leak path (tests/python.py:147-201: one 40 keV photon, two extleak and three
