@@ -90,6 +90,7 @@ struct pc_totals {             /* device-resident totals of one run */
 struct pc_kargs {
 	const double *g_z, *g_cap, *g_zh, *g_cap2, *g_hexd, *g_idz, *g_ext, *g_stp, *g_istp;
 	const pc_marg4 *g_mg;         /* block-certificate record per start node (pc_problem.h) */
+	const pc_drdev *g_dr;         /* leak path: chord deviations of cap per start node */
 	const pc_energy_const *ec;
 	const double *ec_soa;         /* the same constants field-major [6][n_energies]: coalesced loads in the cooperative sweeps */
 	pc_params pm;
@@ -1051,6 +1052,7 @@ struct pc_hip_ctx {
 	pc_energy_const *d_ec = nullptr;
 	double *d_ec_soa = nullptr;
 	pc_marg4 *d_mg = nullptr;              /* block-certificate records, npts */
+	pc_drdev *d_dr = nullptr;              /* leak path: chord deviations of cap, npts */
 	/* options */
 	int literal = 0;
 	int event_threshold = 48;      /* lanes that must be marching for a MARCH burst to run before the waiting EVENTs.  With the short flights of
@@ -1183,6 +1185,7 @@ static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
 	a.g_cap2 = ctx->d_tables + 3*npts; a.g_hexd = ctx->d_tables + 4*npts; a.g_idz = ctx->d_tables + 5*npts;
 	a.g_ext = ctx->d_tables + 6*npts; a.g_stp = ctx->d_tables + 7*npts; a.g_istp = ctx->d_tables + 8*npts;
 	a.g_mg = ctx->d_mg;
+	a.g_dr = ctx->d_dr;
 	a.ec = ctx->d_ec;
 	a.ec_soa = ctx->d_ec_soa;
 	a.pm = ctx->host.pm;
@@ -1372,6 +1375,7 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->d_ec) (void)hipFree(ctx->d_ec);
 	if (ctx->d_ec_soa) (void)hipFree(ctx->d_ec_soa);
 	if (ctx->d_mg) (void)hipFree(ctx->d_mg);
+	if (ctx->d_dr) (void)hipFree(ctx->d_dr);
 	if (ctx->d_totals) (void)hipFree(ctx->d_totals);
 	if (ctx->d_img) (void)hipFree(ctx->d_img);
 	if (ctx->d_soa) (void)hipFree(ctx->d_soa);
@@ -1435,6 +1439,8 @@ int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ou
 		PC_CTX_CHECK(hipMemcpy(ctx->d_tables + k*npts, src[k]->data(), npts*sizeof(double), hipMemcpyHostToDevice));
 	PC_CTX_CHECK(hipMalloc(&ctx->d_mg, npts*sizeof(pc_marg4)));
 	PC_CTX_CHECK(hipMemcpy(ctx->d_mg, ctx->host.mg.data(), npts*sizeof(pc_marg4), hipMemcpyHostToDevice));
+	PC_CTX_CHECK(hipMalloc(&ctx->d_dr, npts*sizeof(pc_drdev)));
+	PC_CTX_CHECK(hipMemcpy(ctx->d_dr, ctx->host.dr.data(), npts*sizeof(pc_drdev), hipMemcpyHostToDevice));
 	{
 		/* at least 8 entries: the register-weight kernels read NE constants whatever n_energies is (surplus = copies of the last) */
 		std::vector<pc_energy_const> ecp(ctx->host.ec);

@@ -403,6 +403,12 @@ PC_HD int pc_wall_begin(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L
 #ifndef PC_WALL_SEGS
 #define PC_WALL_SEGS 300      /* profile segments one unit of the wall search may step through (the rest of a certified stretch waits for the next unit) */
 #endif
+#ifndef PC_WALL_LEVELS
+#define PC_WALL_LEVELS 0   /* widest piece of the wall search: 0 = one profile segment, 1 = PC_L1, 2 = PC_L2 segments.  The wider pieces
+                            * halve the units of a search (host count: 2.0 pieces + 2.0 literal steps per search instead of 4.6 + 2.0) and
+                            * lose on the GPU: the lanes of a unit then step through 1 ... 25 segments each and wait for the longest
+                            * (mean wave life 149 ms against 125 ms for 262144 slots, scripts/ab_leak.sh) */
+#endif
 #ifndef PC_WALL_PIECES
 #define PC_WALL_PIECES 3   /* straight pieces (blocks of 1, PC_L1 or PC_L2 segments) one unit of the wall search may certify */
 #endif
@@ -489,7 +495,7 @@ PC_HD int pc_wall_step(const pc_tables &T, const pc_params &Pm, pc_leak_lane &L,
 			const double room_h = PC_COSPI_6*zh_s - ((s1 > s2) ? ((s1 > s3) ? s1 : s3) : ((s2 > s3) ? s2 : s3));
 			const double uu_s = usx*usx + usy*usy;
 			int lv = 0;
-			for (int l = 1; l <= 2; l++) {
+			for (int l = 1; l <= PC_WALL_LEVELS; l++) {
 				if (is + ((l == 2) ? PC_L2 : PC_L1) > nmax) break;
 				const double al = 4.*((PC_COSPI_6 + kab)*(double)((l == 2) ? g.md2 : g.md1) + (double)((l == 2) ? T.dr[is].d2 : T.dr[is].d1));
 				if (!(al < room_h) || (inside_stack && !(uu_s > (r_s + al)*(r_s + al)))) break;

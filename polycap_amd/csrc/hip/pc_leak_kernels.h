@@ -45,6 +45,7 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 	constexpr int NT = (PITCH <= 1024) ? 9 : 7;      /* the step tables of the wall search fit next to the others up to 1024 points */
 	__shared__ double lds[NT*PITCH];
 	__shared__ pc_marg4 ldsg[PITCH];
+	__shared__ pc_drdev ldsd[(PITCH <= 1024) ? PITCH : 1];
 	const int npts = a.pm.nmax + 1;
 	for (int k = threadIdx.x; k < npts; k += blockDim.x) {
 		lds[k] = a.g_z[k];
@@ -56,6 +57,7 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 		lds[6*PITCH + k] = a.g_ext[k];
 		if (NT == 9) { lds[7*PITCH + k] = a.g_stp[k]; lds[8*PITCH + k] = a.g_istp[k]; }
 		ldsg[k] = a.g_mg[k];
+		if (NT == 9) ldsd[k] = a.g_dr[k];
 	}
 	__syncthreads();
 	pc_tables T;
@@ -63,6 +65,7 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 	T.ext = lds + 6*PITCH;
 	T.stp = (NT == 9) ? lds + 7*PITCH : a.g_stp; T.istp = (NT == 9) ? lds + 8*PITCH : a.g_istp;
 	T.mg = ldsg;
+	T.dr = (NT == 9) ? ldsd : a.g_dr;
 	const pc_params &Pm = a.pm;
 	const int ne = Pm.n_energies;
 	const long long rec = PC_N_FIELDS + (long long)ne;
