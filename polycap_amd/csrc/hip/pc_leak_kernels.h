@@ -19,6 +19,9 @@
 #ifndef PC_LEAK_BLOCK
 #define PC_LEAK_BLOCK 256
 #endif
+#ifndef PC_LEAK_OTHER_REPS
+#define PC_LEAK_OTHER_REPS 2   /* short states a lane may pass in one unit of that class (1 / 2 / 3: mean wave life 125.1 / 122.4 / 125.7 ms) */
+#endif
 #ifndef PC_LEAK_MIN_WAVES
 #define PC_LEAK_MIN_WAVES 1    /* waves per SIMD the register allocator leaves room for */
 #endif
@@ -149,8 +152,13 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 			/* ---- segment visits, reflections with their leak bookkeeping, end of a photon */
 			cls = 3;
 			st_units[3]++; st_lanes[3] += (unsigned)nO;
-			if (mode == PC_LM_RUN && L.st != PC_LS_MARCH && L.st != PC_LS_WALL_STEP && L.st != PC_LS_WALL_PROBE)
-				pc_leak_unit_other(T, Pm, L);
+			/* the short states come in chains (segment visit -> reflection -> ... -> wall search; end of a leaked fraction ->
+			 * its parent's reflection resumed): lanes that walk a chain together take its next link in the same pass */
+#pragma unroll 1
+			for (int rep = 0; rep < PC_LEAK_OTHER_REPS; rep++) {
+				if (mode == PC_LM_RUN && L.st != PC_LS_MARCH && L.st != PC_LS_WALL_STEP && L.st != PC_LS_WALL_PROBE && L.st != PC_LS_DONE)
+					pc_leak_unit_other(T, Pm, L);
+			}
 		} else {
 			/* ---- driver: verdict on finished launches, next attempt or next slot */
 			cls = 4;
