@@ -78,20 +78,22 @@ struct pc_drdev { float d1, d2; };
 
 PC_HD float pc_bits_as_float(unsigned int u) { return __builtin_bit_cast(float, u); }
 
-/* profile tables.  z/cap/zh/cap2 are the MARCH tables (LDS on the device), ext is only read on events. */
+/* profile tables.  z/cap/zh/cap2 are the MARCH tables (LDS on the device), ext is only read on events.  Every kernel sets the
+ * tables its path reads; the rest stay null (a forgotten table then faults in the host compile of the tests instead of reading
+ * whatever the register held). */
 struct pc_tables {
-	const double *z;
-	const double *cap;
-	const double *zh;    /* ext[i] / hexscale: capillary axis = (kx, ky) * zh[i]  (src/polycap-photon.c:624-627) */
-	const double *cap2;  /* cap[i]^2 */
-	const double *hexd;  /* sqrt(ext^2 - (ext/2)^2): centre-to-edge distance of the outer hexagon at node i */
-	const double *idz;   /* 1 / (z[i+1] - z[i]) */
-	const double *ext;
-	const double *stp;   /* leak path: cap[i] / 10, the step of the wall search in segment i (src/polycap-capil.c:1019) */
-	const double *istp;  /* leak path: 10 / cap[i] (candidates for step counts only) */
-	const struct pc_drdev *dr;   /* leak path: chord deviations of cap */
+	const double *z = nullptr;
+	const double *cap = nullptr;
+	const double *zh = nullptr;    /* ext[i] / hexscale: capillary axis = (kx, ky) * zh[i]  (src/polycap-photon.c:624-627) */
+	const double *cap2 = nullptr;  /* cap[i]^2 */
+	const double *hexd = nullptr;  /* sqrt(ext^2 - (ext/2)^2): centre-to-edge distance of the outer hexagon at node i */
+	const double *idz = nullptr;   /* 1 / (z[i+1] - z[i]) */
+	const double *ext = nullptr;
+	const double *stp = nullptr;   /* leak path: cap[i] / 10, the step of the wall search in segment i (src/polycap-capil.c:1019) */
+	const double *istp = nullptr;  /* leak path: 10 / cap[i] (candidates for step counts only) */
+	const struct pc_drdev *dr = nullptr;   /* leak path: chord deviations of cap */
 	/* block certificates (see pc_march_ok): for stride L1 / L2, margin base and chord deviation of zh, rounded up */
-	const struct pc_marg4 *mg;   /* margin base and chord deviation of zh of both strides, packed per start node: one 16-byte read */
+	const struct pc_marg4 *mg = nullptr;   /* margin base and chord deviation of zh of both strides, packed per start node: one 16-byte read */
 };
 
 #ifndef PC_L1
