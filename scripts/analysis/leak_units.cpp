@@ -15,6 +15,8 @@
 #include "pc_leak.h"
 
 long long pc_leak_stats[16];
+long long crit_sum[4], crit_best[2];
+extern "C" long long *leak_crit(void) { static long long r[6]; for (int k = 0; k < 4; k++) r[k] = crit_sum[k]; r[4] = crit_best[0]; r[5] = crit_best[1]; return r; }
 extern "C" long long *leak_stats(void) { return pc_leak_stats; }
 
 extern "C" int leak_units(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int64_t n_slots, int max_depth,
@@ -51,12 +53,39 @@ extern "C" int leak_units(const pc_hip_problem *p, uint64_t seed, int64_t slot0,
 				int st = pc_launch_init(T, Pm, ph, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez);
 				cx.slot = (double)(slot0 + j); cx.attempt = (double)attempt;
 				pc_leak_begin(T, Pm, L, st, s.z);
+				/* critical path of the attempt if every leaked fraction were traced by a lane of its own from the moment it is
+				 * spawned: own[l] = units of the photon at level l so far, kid[l] = latest end among its finished children */
+				std::vector<long long> own(1, 0), kid(1, 0), at(1, 0);
+				long long att_units = 0;
+				int prev_lvl = 0;
 				while (L.st != PC_LS_DONE) {
+					if (L.lvl > prev_lvl) { own.push_back(0); kid.push_back(0); at.push_back(own[prev_lvl]); }
+					else if (L.lvl < prev_lvl) {
+						while ((int)own.size() - 1 > L.lvl) {
+							const long long c = std::max(own.back(), kid.back()), a0 = at.back();
+							own.pop_back(); kid.pop_back(); at.pop_back();
+							kid.back() = std::max(kid.back(), a0 + c);
+						}
+					}
+					prev_lvl = L.lvl;
+					own[L.lvl]++; att_units++;
 					if (L.lvl > o[5]) o[5] = L.lvl;
 					if (L.st == PC_LS_MARCH) { o[0]++; pc_leak_unit_march(T, Pm, L); }
 					else if (L.st == PC_LS_WALL_STEP) { o[1]++; L.st = pc_wall_step(T, Pm, L, L.after_wall); }
 					else if (L.st == PC_LS_WALL_PROBE) { o[2]++; L.st = pc_wall_probe(T, Pm, L, L.after_wall); }
 					else { o[3]++; pc_leak_unit_other(T, Pm, L); }
+				}
+				while (own.size() > 1) {
+					const long long c = std::max(own.back(), kid.back()), a0 = at.back();
+					own.pop_back(); kid.pop_back(); at.pop_back();
+					kid.back() = std::max(kid.back(), a0 + c);
+				}
+				{
+					const long long crit = std::max(own[0], kid[0]);
+					if (att_units > crit_best[0]) { crit_best[0] = att_units; crit_best[1] = crit; }
+					__atomic_fetch_add(&crit_sum[0], att_units, __ATOMIC_RELAXED);
+					__atomic_fetch_add(&crit_sum[1], crit, __ATOMIC_RELAXED);
+					if (att_units > 5000) { __atomic_fetch_add(&crit_sum[2], att_units, __ATOMIC_RELAXED); __atomic_fetch_add(&crit_sum[3], crit, __ATOMIC_RELAXED); }
 				}
 				o[4]++;
 				if (L.rc == 1 && pc_in_exit_window(Pm, ph)) break;

@@ -42,3 +42,7 @@ names = ["wall step: certified block", "wall step: literal step", "cell changes 
 print("units of the wall search by outcome, per wall search:")
 for k, nm in enumerate(names):
     print("  %-36s %10d  %7.2f" % (nm % ((5, 25)[k - 4],) if "%d" in nm else nm, st[k], st[k] / max(1, st[8])))
+L.leak_crit.restype = C.POINTER(C.c_longlong * 6)
+cr = list(L.leak_crit().contents)
+print("critical path of an attempt if every leaked fraction had a lane of its own from its spawn: all attempts %.3g of %.3g units (%.2f);"
+      " attempts above 5000 units %.3g of %.3g (%.2f); the longest attempt %d of %d" % (cr[1], cr[0], cr[1] / max(1, cr[0]), cr[3], cr[2], cr[3] / max(1, cr[2]), cr[5], cr[4]))
