@@ -97,6 +97,10 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
  *   "keep_pinned"      pc_hip_transmission_images leaves the destination planes it pinned (hipHostRegister) pinned: the
  *                      caller reuses them for later runs and unpins them with pc_hip_host_unregister before freeing them
  *   "slot_ids"         compact runs also record which slot sits at which position (pc_hip_transmission_slot_ids)
+ *   "leak_order"       leak_calc source runs with two to five slots per lane hand out their slots heaviest first, predicted by
+ *                      a plain pre-pass of the same slots, the heaviest n/400 to lanes of their own (default 1; 0 = slot order)
+ *   "leak_heavy_lanes", "leak_heavy_every", "leak_heavy_company", "leak_park_units"   tuning of that (defaults 1, 1, 0, 0)
+ *   "leak_slot_units"  leak_calc source runs keep the units of work per slot (pc_hip_leak_slot_units)
  *   "batch_reflections" many-energy source runs: sweep a photon's weights once per four reflections (default 1)
  *   "fetch_threads"    host threads of the staging fallback of the image fetch (0 = min(16, cores))
  *   leak runs: "leak_max_depth" (stack frames per lane = walls one photon may cross), "leak_stack_mb" (HBM for those
@@ -142,6 +146,13 @@ POLYCAP_EXTERN void pc_hip_host_unregister(void *ptr);
 /* Slot (relative to slot0 of the last run) of the photon stored at positions [first, first+count) of the image planes:
  * the identity unless the run was compact ("compact_images" with "slot_ids"). */
 POLYCAP_EXTERN int pc_hip_transmission_slot_ids(pc_hip_ctx *ctx, int64_t first, int64_t count, int64_t *slots);
+/* leak_calc runs (reference: the static split of the photon loop over OpenMP threads, src/polycap-source.c:744): the order in
+ * which the next source runs of exactly n slots hand out their slots -- a permutation of 0 .. n-1, heaviest slot first; the
+ * first n_heavy of them are traced by a few lanes of every fourth wave (options leak_heavy_lanes, leak_heavy_every).  n = 0
+ * restores slot order.  Results do not depend on the order.  pc_hip_leak_slot_units: units of work the last leak run (option
+ * leak_slot_units = 1) spent on each slot. */
+POLYCAP_EXTERN int pc_hip_leak_set_order(pc_hip_ctx *ctx, const uint32_t *order, int64_t n, int64_t n_heavy);
+POLYCAP_EXTERN int pc_hip_leak_slot_units(pc_hip_ctx *ctx, int64_t first, int64_t count, uint32_t *units);
 
 /* ---- leak_calc = true ("halo" photons): src/polycap-capil.c:610-619, 657-1194, src/polycap-photon.c:171-362, 645-907,
  * src/polycap-source.c:799-879, 925-1032.  Same calls with the fraction of every reflection that is transmitted through

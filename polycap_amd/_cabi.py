@@ -142,6 +142,10 @@ def lib():
     L.pc_hip_transmission_records.restype = C.c_int
     L.pc_hip_transmission_slot_ids.argtypes = [C.c_void_p, C.c_int64, C.c_int64, c_int64_p]
     L.pc_hip_transmission_slot_ids.restype = C.c_int
+    L.pc_hip_leak_set_order.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int64, C.c_int64]
+    L.pc_hip_leak_set_order.restype = C.c_int
+    L.pc_hip_leak_slot_units.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint32)]
+    L.pc_hip_leak_slot_units.restype = C.c_int
     L.pc_hip_phase_stats.argtypes = [C.c_void_p, c_int64_p]
     L.pc_hip_phase_stats.restype = C.c_int
     L.pc_hip_last_kernel.argtypes = [C.c_void_p]

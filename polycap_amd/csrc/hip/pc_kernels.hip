@@ -91,6 +91,7 @@ struct pc_kargs {
 	const double *g_z, *g_cap, *g_zh, *g_cap2, *g_hexd, *g_idz, *g_ext, *g_stp, *g_istp;
 	const pc_marg4 *g_mg;         /* block-certificate record per start node (pc_problem.h) */
 	const pc_drdev *g_dr;         /* leak path: chord deviations of cap per start node */
+	unsigned int *work_est;       /* [n_slots] or null: reflections + 1 of every attempt, summed per slot (lane kernels, source runs) */
 	const pc_energy_const *ec;
 	const double *ec_soa;         /* the same constants field-major [6][n_energies]: coalesced loads in the cooperative sweeps */
 	pc_params pm;
@@ -687,6 +688,10 @@ pc_trace_kernel(pc_kargs a)
 					if (rc == 0) f_not_trans = 1;
 					else if (rc == 2) f_not_entered = 1;
 					else if (rc == 1) ok = pc_in_exit_window(Pm, ph);
+					if constexpr (!BATCH) {
+						/* what a leak run of the same slots is ordered by (pc_leak_auto_order) */
+						if (a.work_est) atomicAdd(&a.work_est[slot], (unsigned int)ph.irefl + 1u);
+					}
 				}
 			}
 			/* compact store: the exit photons of this phase take the next positions of the planes, one coalesced run per plane */
@@ -1161,6 +1166,18 @@ struct pc_hip_ctx {
 	unsigned long long *d_leak_timing = nullptr;   /* POLYCAP_LEAK_TIMING diagnostics */
 	size_t leak_timing_bytes = 0;
 	long long leak_timing_waves = 0;
+	unsigned int *d_leak_order = nullptr;  /* order in which the next leak run hands out its slots (pc_hip_leak_set_order) */
+	int leak_order = 1;                    /* option: 1 = source runs of >= 196608 slots order their slots by a plain pre-pass, 0 = slot order */
+	int leak_order_user = 0;               /* the order was set by the caller */
+	unsigned long long leak_order_seed = 0; long long leak_order_slot0 = -1; unsigned int leak_order_attempts = 0;   /* what the automatic order was made for */
+	unsigned int *d_work_est = nullptr; long long work_est_n = 0, leak_order_cap = 0;
+	int leak_ev0_done = 0;                 /* ev0 of the run in flight was recorded before its pre-pass */
+	long long leak_order_n = 0, leak_n_heavy = 0;
+	int leak_heavy_lanes = 1, leak_heavy_every = 1, leak_heavy_company = 0;
+	long long leak_park_units = 0;
+	int leak_slot_units = 0;               /* option: keep the units of work per slot of leak runs (pc_hip_leak_slot_units) */
+	unsigned int *d_leak_slot_units = nullptr;
+	long long leak_slot_units_n = 0;
 	long long leak_attempt_slots = 0;
 	int leak_pending = 0;                  /* a leak transmission run is in flight: wait() collects its events */
 	unsigned long long leak_seed = 0;
@@ -1351,6 +1368,7 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 #include "pc_leak_kernels.h"
 
 static int pc_transmission_enqueue_leak(pc_hip_ctx *ctx);
+static int pc_leak_auto_order(pc_hip_ctx *ctx);
 
 extern "C" {
 
@@ -1402,6 +1420,9 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->d_amu) (void)hipFree(ctx->d_amu);
 	if (ctx->d_leak_attempts) (void)hipFree(ctx->d_leak_attempts);
 	if (ctx->d_leak_timing) (void)hipFree(ctx->d_leak_timing);
+	if (ctx->d_leak_order) (void)hipFree(ctx->d_leak_order);
+	if (ctx->d_work_est) (void)hipFree(ctx->d_work_est);
+	if (ctx->d_leak_slot_units) (void)hipFree(ctx->d_leak_slot_units);
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1502,6 +1523,12 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "pool_march_min") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "pool_march_min must be in [1,64]"); ctx->pool_march_min = (int)value; }
 	else if (n == "leak_max_depth") { if (value < 2 || value > (1 << 20)) return pc_fail(PC_HIP_ERR_INVALID, "leak_max_depth must be in [2, 2^20]"); ctx->leak_max_depth = (int)value; }
 	else if (n == "leak_stack_mb") { if (value < 1) return pc_fail(PC_HIP_ERR_INVALID, "leak_stack_mb must be >= 1"); ctx->leak_stack_bytes = (size_t)value << 20; }
+	else if (n == "leak_order") { ctx->leak_order = value != 0; }
+	else if (n == "leak_slot_units") { ctx->leak_slot_units = value != 0; }
+	else if (n == "leak_heavy_lanes") { if (value < 0 || value > PC_WAVE) return pc_fail(PC_HIP_ERR_INVALID, "leak_heavy_lanes must be in 0..64"); ctx->leak_heavy_lanes = (int)value; }
+	else if (n == "leak_park_units") { if (value < 0) return pc_fail(PC_HIP_ERR_INVALID, "leak_park_units must be >= 0"); ctx->leak_park_units = (long long)value; }
+	else if (n == "leak_heavy_company") { if (value < 0 || value > PC_WAVE) return pc_fail(PC_HIP_ERR_INVALID, "leak_heavy_company must be in 0..64"); ctx->leak_heavy_company = (int)value; }
+	else if (n == "leak_heavy_every") { if (value < 0) return pc_fail(PC_HIP_ERR_INVALID, "leak_heavy_every must be >= 0"); ctx->leak_heavy_every = (int)value; }
 	else if (n == "leak_capacity") { if (value < 0) return pc_fail(PC_HIP_ERR_INVALID, "leak_capacity must be >= 0"); ctx->leak_capacity = (long long)value; }
 	else return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_set_option: unknown option " + n);
 	return PC_HIP_OK;
@@ -1570,6 +1597,7 @@ static int pc_launch_photons_impl(pc_hip_ctx *ctx, int64_t n, const double *star
 			ctx->leak_slot0 = 0;
 			for (;;) {
 				ctx->leak_capacity_used = capacity;
+				ctx->leak_ev0_done = 0;
 				status = pc_leak_enqueue<PC_MODE_EXPLICIT>(ctx, a, n, capacity);
 				if (status) goto done;
 				PC_LP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1888,7 +1916,10 @@ int pc_hip_transmission_run_leak(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, 
 	 * 9 per slot at one energy, 29 at seven on the reference's test optic; a run that outgrows the buffer is repeated, so
 	 * the first guess is generous (16 + 8 n_energies records per slot) */
 	ctx->leak_capacity_used = ctx->leak_capacity > 0 ? ctx->leak_capacity : std::max<long long>(65536, (16 + 8*(long long)ne)*n_slots);
-	int status = pc_transmission_enqueue_leak(ctx);
+	ctx->leak_ev0_done = 0;
+	int status = pc_leak_auto_order(ctx);
+	if (status) return status;
+	status = pc_transmission_enqueue_leak(ctx);
 	if (status) return status;
 	ctx->run_slots = n_slots;
 	ctx->run_pending = 1;
@@ -2363,6 +2394,41 @@ int pc_hip_transmission_slot_ids(pc_hip_ctx *ctx, int64_t first, int64_t count, 
 	return PC_HIP_OK;
 }
 
+int pc_hip_leak_set_order(pc_hip_ctx *ctx, const uint32_t *order, int64_t n, int64_t n_heavy)
+{
+	if (!ctx || n < 0 || (n > 0 && !order) || n_heavy < 0) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_leak_set_order: invalid argument");
+	PC_HIP_CHECK(hipSetDevice(ctx->device));
+	int st = pc_hip_transmission_wait(ctx, nullptr);
+	if (st) return st;
+	if (ctx->d_leak_order) { PC_HIP_CHECK(hipFree(ctx->d_leak_order)); ctx->d_leak_order = nullptr; }
+	ctx->leak_order_n = 0; ctx->leak_n_heavy = 0; ctx->leak_order_user = 0; ctx->leak_order_slot0 = -1;
+	if (n == 0) return PC_HIP_OK;
+	{
+		/* a permutation of 0 .. n-1, or slots would be traced twice or not at all */
+		std::vector<unsigned char> seen((size_t)n, 0);
+		for (int64_t k = 0; k < n; k++) {
+			if ((int64_t)order[k] >= n || seen[order[k]]) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_leak_set_order: order is not a permutation of the slots");
+			seen[order[k]] = 1;
+		}
+	}
+	PC_HIP_CHECK(hipMalloc(&ctx->d_leak_order, (size_t)n*sizeof(unsigned int)));
+	ctx->leak_order_cap = n;
+	PC_HIP_CHECK(hipMemcpy(ctx->d_leak_order, order, (size_t)n*sizeof(unsigned int), hipMemcpyHostToDevice));
+	ctx->leak_order_n = n; ctx->leak_n_heavy = n_heavy; ctx->leak_order_user = 1;
+	return PC_HIP_OK;
+}
+
+int pc_hip_leak_slot_units(pc_hip_ctx *ctx, int64_t first, int64_t count, uint32_t *units)
+{
+	if (!ctx || (count > 0 && !units) || first < 0 || count < 0) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_leak_slot_units: invalid argument");
+	int st = pc_hip_transmission_wait(ctx, nullptr);
+	if (st) return st;
+	if (!ctx->d_leak_slot_units || first + count > ctx->leak_slot_units_n) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_leak_slot_units: no leak run with the option leak_slot_units covers this range");
+	PC_HIP_CHECK(hipSetDevice(ctx->device));
+	if (count) PC_HIP_CHECK(hipMemcpy(units, ctx->d_leak_slot_units + first, (size_t)count*sizeof(unsigned int), hipMemcpyDeviceToHost));
+	return PC_HIP_OK;
+}
+
 int pc_hip_transmission_records(pc_hip_ctx *ctx, int64_t first, int64_t count, double *records)
 {
 	if (!ctx || !records) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_transmission_records: NULL argument");
@@ -2394,6 +2460,100 @@ int pc_hip_device_synchronize(pc_hip_ctx *ctx)
 } /* extern "C" */
 
 #include "pc_group.h"
+
+/* Heaviest slots first.  A leak launch ends with its longest slot: 20 000 units of work on one lane, which advances several
+ * times faster alone in its wave than among 63 others (a wave runs one class of work at a time).  Which slots are long is known
+ * beforehand to a good approximation (correlation 0.95 with the units of the leak run, scripts/analysis/leak_units.py): a plain
+ * run of the same slots -- the same photons without their leaks, a hundredth of the leak run's time -- counts the reflections
+ * of every attempt per slot.  The slots are then handed out in descending order of that count, the first n/400 of them to lane
+ * 0 of the waves, whose other lanes wait while such a slot is at work (pc_leak_kargs::order).  The results do not depend on the
+ * order (photon streams are keyed by slot and attempt, events are ordered by slot on the host). */
+static int pc_leak_auto_order(pc_hip_ctx *ctx)
+{
+	const long long n = ctx->leak_n_slots;
+	if (ctx->leak_order_user) return PC_HIP_OK;                       /* the caller's order (used if it is for n slots) */
+	long long lanes = 0;
+	(void)pc_leak_grid(ctx, n, lanes);
+	/* considered when every lane gets two to five slots: with fewer there is nothing to order, with more the launch is not bound
+	 * by its longest slot (the check below, made beforehand with the reference optic's ratio of longest to mean slot, 11.6) */
+	if (!ctx->leak_order || n < 2*lanes || n >= 5*lanes || n >= (1ll << 32)) {
+		if (ctx->d_leak_order) { PC_HIP_CHECK(hipFree(ctx->d_leak_order)); ctx->d_leak_order = nullptr; }
+		ctx->leak_order_n = 0; ctx->leak_order_slot0 = -1; ctx->leak_order_cap = 0;
+		return PC_HIP_OK;
+	}
+	if (ctx->d_leak_order && ctx->leak_order_n == n && ctx->leak_order_seed == ctx->leak_seed && ctx->leak_order_slot0 == ctx->leak_slot0
+	    && ctx->leak_order_attempts == ctx->leak_max_attempts)
+		return PC_HIP_OK;                                               /* the same slots as last time */
+	if (ctx->work_est_n < n) {
+		if (ctx->d_work_est) PC_HIP_CHECK(hipFree(ctx->d_work_est));
+		ctx->d_work_est = nullptr; ctx->work_est_n = 0;
+		if (hipMalloc(&ctx->d_work_est, (size_t)n*sizeof(unsigned int)) != hipSuccess) return pc_fail(PC_HIP_ERR_MEMORY, "leak run: could not allocate the work estimate");
+		ctx->work_est_n = n;
+	}
+	const bool tim = getenv("POLYCAP_LEAK_TIMING") != nullptr;
+	const auto t_0 = std::chrono::steady_clock::now();
+	/* the time of the launch starts here */
+	PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+	ctx->leak_ev0_done = 1;
+	PC_HIP_CHECK(hipMemsetAsync(ctx->d_work_est, 0, (size_t)n*sizeof(unsigned int), ctx->stream));
+	PC_HIP_CHECK(hipMemsetAsync(ctx->d_totals, 0, ctx->totals_bytes, ctx->stream));
+	pc_kargs a;
+	pc_fill_common(ctx, a);
+	a.seed = ctx->leak_seed; a.max_attempts = ctx->leak_max_attempts; a.keep_images = 0;
+	a.slot0 = ctx->leak_slot0; a.n_slots = n;
+	pc_set_img(ctx, a, 0, n, false, false);
+	a.work_est = ctx->d_work_est;
+	struct restore_ctx {          /* the lane kernel, no events of its own */
+		pc_hip_ctx *c; int producer, pool;
+		~restore_ctx() { c->producer = producer; c->pool = pool; c->rec_ev0 = c->rec_ev1 = true; }
+	} restore{ctx, ctx->producer, ctx->pool};
+	ctx->producer = 0; ctx->pool = 0; ctx->rec_ev0 = ctx->rec_ev1 = false;
+	int st = ctx->host.pm.generic_src ? pc_launch_kernel<PC_MODE_SRC_GENERIC>(ctx, a, n) : pc_launch_kernel<PC_MODE_SRC_CIRCULAR>(ctx, a, n);
+	if (st) return st;
+	std::vector<unsigned int> est((size_t)n);
+	PC_HIP_CHECK(hipMemcpyAsync(est.data(), ctx->d_work_est, (size_t)n*sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+	PC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	const auto t_1 = std::chrono::steady_clock::now();
+	/* Is the launch bound by its longest slot?  A lone lane works through a unit in about 4 us, a lane among the 64 of a busy wave
+	 * in about 13 us: with the slots in slot order the launch lasts about (all work / lanes) x 13 us, the longest slot alone
+	 * (its work) x 4 us.  When the second is not most of the first (launches of many slots per lane), handing the heaviest slots
+	 * to lanes of their own only takes lanes away from the rest: slot order stays (measured: 524288 and 1048576 slots lose 4-7 %,
+	 * 262144 gain 10-15 %). */
+	unsigned int top = 0;
+	unsigned long long total = 0;
+	for (long long k = 0; k < n; k++) { if (est[(size_t)k] > top) top = est[(size_t)k]; total += est[(size_t)k]; }
+	if (!((double)top * 4.0 * (double)lanes > 0.8 * 13.0 * (double)total)) {
+		ctx->leak_order_n = 0; ctx->leak_order_slot0 = -1;      /* the buffer stays for the next run; it is not used */
+		if (tim) fprintf(stderr, "leak order: slot order kept (longest slot %u of %llu predicted units, %lld lanes)\n", top, total, lanes);
+		return PC_HIP_OK;
+	}
+	/* descending counting sort (stable: equal counts keep slot order) */
+	std::vector<unsigned int> order((size_t)n);
+	if (top < (1u << 22)) {
+		std::vector<unsigned int> first((size_t)top + 2, 0);
+		for (long long k = 0; k < n; k++) first[(size_t)(top - est[(size_t)k]) + 1]++;
+		for (size_t v = 0; v + 1 < first.size(); v++) first[v + 1] += first[v];
+		for (long long k = 0; k < n; k++) order[first[(size_t)(top - est[(size_t)k])]++] = (unsigned int)k;
+	} else {
+		for (long long k = 0; k < n; k++) order[(size_t)k] = (unsigned int)k;
+		std::stable_sort(order.begin(), order.end(), [&](unsigned int x, unsigned int y) { return est[x] > est[y]; });
+	}
+	const auto t_2 = std::chrono::steady_clock::now();
+	if (ctx->d_leak_order && ctx->leak_order_cap < n) { PC_HIP_CHECK(hipFree(ctx->d_leak_order)); ctx->d_leak_order = nullptr; }
+	if (!ctx->d_leak_order) { PC_HIP_CHECK(hipMalloc(&ctx->d_leak_order, (size_t)n*sizeof(unsigned int))); ctx->leak_order_cap = n; }
+	PC_HIP_CHECK(hipMemcpyAsync(ctx->d_leak_order, order.data(), (size_t)n*sizeof(unsigned int), hipMemcpyHostToDevice, ctx->stream));
+	PC_HIP_CHECK(hipStreamSynchronize(ctx->stream));      /* `order` leaves scope */
+	if (tim) {
+		const auto t_3 = std::chrono::steady_clock::now();
+		auto ms = [](auto x, auto y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+		fprintf(stderr, "leak order: plain pre-pass + copy %.2f ms, sort %.2f ms, upload %.2f ms\n", ms(t_0, t_1), ms(t_1, t_2), ms(t_2, t_3));
+	}
+	ctx->leak_order_n = n;
+	/* one heavy slot per wave at most: the wave is the heavy lane's alone while it lasts */
+	ctx->leak_n_heavy = std::min<long long>(n / 400, (long long)ctx->n_cu * 2);
+	ctx->leak_order_seed = ctx->leak_seed; ctx->leak_order_slot0 = ctx->leak_slot0; ctx->leak_order_attempts = ctx->leak_max_attempts;
+	return PC_HIP_OK;
+}
 
 static int pc_transmission_enqueue_leak(pc_hip_ctx *ctx)
 {

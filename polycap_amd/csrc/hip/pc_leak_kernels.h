@@ -35,10 +35,21 @@ struct pc_leak_kargs {
 	long long capacity;
 	unsigned int *final_attempt;   /* [n_slots]: attempt index of the transmitted photon of each slot (driver mode) */
 	unsigned long long *timing;    /* diagnostics (POLYCAP_LEAK_TIMING): 8 clock sums per wave, or null */
+	/* order in which the slots are handed out (source runs): order[k] = relative slot index, heaviest first, or null = 0, 1, 2, ...
+	 * The first n_heavy of them go to lanes 0 .. heavy_lanes-1 of every heavy_every-th wave, whose other lanes stay out of work
+	 * while that tier lasts: a slot of 20 000 units of work on a lane that shares its wave with three others advances several
+	 * times faster than among 63, and it is the heaviest slots that decide when the launch ends.  cursor[2], cursor[3]: positions
+	 * handed out in the heavy tier and behind it. */
+	const unsigned int *order;
+	long long n_heavy;
+	int heavy_lanes, heavy_every;
+	int heavy_company;             /* lanes of a heavy wave that may work on light slots beside its heavy lanes */
+	unsigned int park_units;       /* a lane whose slot has taken more units than this gets its wave to itself (0 = never) */
+	unsigned int *slot_units;      /* [n_slots] units of work spent on each slot (what the next run of the same slots is ordered by), or null */
 };
 
 /* lane modes of the scheduler on top of pc_leak_lane::st */
-enum { PC_LM_NEED = 0, PC_LM_RUN = 1, PC_LM_IDLE = 2 };
+enum { PC_LM_NEED = 0, PC_LM_RUN = 1, PC_LM_IDLE = 2, PC_LM_PARKED = 3 };
 
 template <int MODE, int PITCH>
 __global__ void __launch_bounds__(PC_LEAK_BLOCK, PC_LEAK_MIN_WAVES)
@@ -90,6 +101,9 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 	int launched = 0;                 /* a launch of this lane has finished and waits for the driver's verdict */
 	long long slot = -1;
 	unsigned int attempt = 0;
+	unsigned int my_units = 0;           /* units of work of this lane since it took its slot */
+	int my_heavy = 0;                    /* the slot of this lane comes from the heavy tier */
+	const bool heavy_wave = lk.order && lk.heavy_every > 0 && ((gtid / PC_WAVE) % lk.heavy_every) == 0;
 	double cosalpha0 = 0.;
 	unsigned int n_exit = 0, n_not_entered = 0, n_not_trans = 0, n_failed = 0, n_launch = 0;
 	unsigned long long s_irefl = 0;
@@ -120,8 +134,10 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 			cls = 0;
 			const int stop = (nS + 1) / 2;
 			for (int b = 0; b < 32; b++) {
-				if (mode == PC_LM_RUN && L.st == PC_LS_WALL_STEP)
+				if (mode == PC_LM_RUN && L.st == PC_LS_WALL_STEP) {
 					L.st = pc_wall_step(T, Pm, L, L.after_wall);
+					my_units++;
+				}
 				const int c = __popcll(__ballot(mode == PC_LM_RUN && L.st == PC_LS_WALL_STEP));
 				st_units[0]++; st_lanes[0] += (unsigned)c;
 				if (c < stop) break;
@@ -131,8 +147,10 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 			cls = 1;
 			const int stop = (nP + 1) / 2;
 			for (int b = 0; b < 32; b++) {
-				if (mode == PC_LM_RUN && L.st == PC_LS_WALL_PROBE)
+				if (mode == PC_LM_RUN && L.st == PC_LS_WALL_PROBE) {
 					L.st = pc_wall_probe(T, Pm, L, L.after_wall);
+					my_units++;
+				}
 				const int c = __popcll(__ballot(mode == PC_LM_RUN && L.st == PC_LS_WALL_PROBE));
 				st_units[1]++; st_lanes[1] += (unsigned)c;
 				if (c < stop) break;
@@ -142,8 +160,10 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 			cls = 2;
 			const int stop = (nM + 1) / 2;
 			for (int b = 0; b < 32; b++) {
-				if (mode == PC_LM_RUN && L.st == PC_LS_MARCH)
+				if (mode == PC_LM_RUN && L.st == PC_LS_MARCH) {
 					pc_leak_unit_march(T, Pm, L);
+					my_units++;
+				}
 				const int c = __popcll(__ballot(mode == PC_LM_RUN && L.st == PC_LS_MARCH));
 				st_units[2]++; st_lanes[2] += (unsigned)c;
 				if (c < stop) break;
@@ -156,12 +176,17 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 			 * its parent's reflection resumed): lanes that walk a chain together take its next link in the same pass */
 #pragma unroll 1
 			for (int rep = 0; rep < PC_LEAK_OTHER_REPS; rep++) {
-				if (mode == PC_LM_RUN && L.st != PC_LS_MARCH && L.st != PC_LS_WALL_STEP && L.st != PC_LS_WALL_PROBE && L.st != PC_LS_DONE)
+				if (mode == PC_LM_RUN && L.st != PC_LS_MARCH && L.st != PC_LS_WALL_STEP && L.st != PC_LS_WALL_PROBE && L.st != PC_LS_DONE) {
 					pc_leak_unit_other(T, Pm, L);
+					my_units++;
+				}
 			}
 		} else {
 			/* ---- driver: verdict on finished launches, next attempt or next slot */
 			cls = 4;
+			if (mode == PC_LM_PARKED) mode = PC_LM_NEED;            /* parked beside the heavy lanes of its wave: look again */
+			/* lanes of this wave that are at work on a slot of the heavy tier and will still be after this pass */
+			const unsigned long long heavy_busy = __ballot((my_heavy || (lk.park_units && my_units > lk.park_units)) && (mode == PC_LM_RUN || (mode == PC_LM_NEED && launched)));
 			if (mode == PC_LM_NEED) {
 				int need_slot = 1;
 				if (launched) {
@@ -221,11 +246,37 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 					}
 				}
 				if (need_slot) {
-					slot = (long long)atomicAdd(&a.totals->next_slot, 1ull);
+					if (!EXPLICIT && lk.slot_units && slot >= 0 && slot < a.n_slots) lk.slot_units[slot] = my_units;
+					my_units = 0;
 					attempt = 0;
-					if (slot >= a.n_slots) mode = PC_LM_IDLE;
+					if (EXPLICIT || !lk.order) {
+						slot = (long long)atomicAdd(&a.totals->next_slot, 1ull);
+						if (slot >= a.n_slots) mode = PC_LM_IDLE;
+					} else {
+						const bool heavy_lane = heavy_wave && lane < lk.heavy_lanes;
+						long long pos = -1;
+						int park = 0;
+						my_heavy = 0;
+						if (heavy_lane) {
+							pos = (long long)atomicAdd(&lk.cursor[2], 1ull);
+							if (pos >= lk.n_heavy) pos = -1; else my_heavy = 1;
+						} else if ((heavy_busy & ~(1ull << lane)) != 0ull
+						           || (heavy_wave && (long long)__hip_atomic_load(&lk.cursor[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lk.n_heavy)) {
+							park = 1;                                    /* the heavy lanes of this wave have the wave to themselves */
+						}
+						if (pos < 0 && !park) {
+							pos = lk.n_heavy + (long long)atomicAdd(&lk.cursor[3], 1ull);
+							if (pos >= a.n_slots) {
+								/* nothing light left: whatever is left of the heavy tier */
+								pos = (long long)atomicAdd(&lk.cursor[2], 1ull);
+								if (pos >= lk.n_heavy) pos = -1;
+							}
+						}
+						if (pos >= 0) slot = (long long)lk.order[pos];
+						else { slot = -1; mode = park ? PC_LM_PARKED : PC_LM_IDLE; }
+					}
 				}
-				if (mode != PC_LM_IDLE) {
+				if (mode != PC_LM_IDLE && mode != PC_LM_PARKED) {
 					/* start an attempt */
 					n_launch++;
 					double z0;
@@ -327,7 +378,7 @@ static int pc_leak_buffers(pc_hip_ctx *ctx, long long lanes, long long capacity,
 		ctx->leak_records_elems = recs;
 	}
 	if (!ctx->d_leak_cursor) {
-		if (hipMalloc(&ctx->d_leak_cursor, 2*sizeof(unsigned long long)) != hipSuccess)
+		if (hipMalloc(&ctx->d_leak_cursor, 4*sizeof(unsigned long long)) != hipSuccess)
 			return pc_fail(PC_HIP_ERR_MEMORY, "leak run: could not allocate the record cursor");
 	}
 	if (!ctx->d_amu) {
@@ -357,6 +408,21 @@ static int pc_leak_enqueue(pc_hip_ctx *ctx, pc_kargs &a, long long n_items, long
 	lk.records = ctx->d_leak_records; lk.cursor = ctx->d_leak_cursor; lk.capacity = capacity;
 	lk.final_attempt = ctx->d_leak_attempts;
 	lk.timing = nullptr;
+	lk.order = nullptr; lk.n_heavy = 0; lk.heavy_lanes = 0; lk.heavy_every = 0; lk.heavy_company = 0; lk.park_units = 0; lk.slot_units = nullptr;
+	if (MODE != PC_MODE_EXPLICIT) {
+		if (ctx->d_leak_order && ctx->leak_order_n == n_items) {
+			lk.order = ctx->d_leak_order;
+			lk.heavy_lanes = ctx->leak_heavy_lanes; lk.heavy_every = ctx->leak_heavy_every; lk.heavy_company = ctx->leak_heavy_company;
+			lk.park_units = (unsigned int)ctx->leak_park_units;
+			lk.n_heavy = (lk.heavy_lanes > 0 && lk.heavy_every > 0) ? std::min<long long>(ctx->leak_n_heavy, n_items) : 0;
+		}
+		if (ctx->leak_slot_units) {
+			if (ctx->d_leak_slot_units && ctx->leak_slot_units_n < n_items) { (void)hipFree(ctx->d_leak_slot_units); ctx->d_leak_slot_units = nullptr; }
+			if (!ctx->d_leak_slot_units) { PC_HIP_CHECK(hipMalloc(&ctx->d_leak_slot_units, (size_t)n_items*sizeof(unsigned int))); ctx->leak_slot_units_n = n_items; }
+			PC_HIP_CHECK(hipMemsetAsync(ctx->d_leak_slot_units, 0, (size_t)n_items*sizeof(unsigned int), ctx->stream));
+			lk.slot_units = ctx->d_leak_slot_units;
+		}
+	}
 	if (getenv("POLYCAP_LEAK_TIMING")) {
 		/* diagnostics: where the waves of the leak kernel spend their time (printed by pc_leak_collect) */
 		const size_t nb = (size_t)(lanes / PC_WAVE) * 8 * sizeof(unsigned long long);
@@ -367,9 +433,9 @@ static int pc_leak_enqueue(pc_hip_ctx *ctx, pc_kargs &a, long long n_items, long
 		ctx->leak_timing_waves = lanes / PC_WAVE;
 	}
 	a.total_threads = lanes;
-	PC_HIP_CHECK(hipMemsetAsync(ctx->d_leak_cursor, 0, 2*sizeof(unsigned long long), ctx->stream));
+	PC_HIP_CHECK(hipMemsetAsync(ctx->d_leak_cursor, 0, 4*sizeof(unsigned long long), ctx->stream));
 	PC_HIP_CHECK(hipMemsetAsync(ctx->d_totals, 0, ctx->totals_bytes, ctx->stream));
-	PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+	if (!ctx->leak_ev0_done) PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
 	if (ctx->host.pm.nmax + 1 <= 1024)
 		hipLaunchKernelGGL((pc_leak_kernel<MODE, 1024>), dim3(grid), dim3(PC_LEAK_BLOCK), 0, ctx->stream, a, lk);
 	else

@@ -204,6 +204,23 @@ class TraceContext:
             raise HipError("pc_hip_transmission_slot_ids", st)
         return ids
 
+    def leak_set_order(self, order, n_heavy=0):
+        """Order in which the next leak_calc source runs of len(order) slots hand out their slots (heaviest first); the first
+        n_heavy go to the heavy lanes.  An empty order restores slot order."""
+        o = np.ascontiguousarray(order, dtype=np.uint32)
+        st = self._L.pc_hip_leak_set_order(self._h, o.ctypes.data_as(C.POINTER(C.c_uint32)), int(o.size), int(n_heavy))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_leak_set_order", st)
+
+    def leak_slot_units(self, first=0, count=None):
+        """Units of work per slot of the last leak_calc source run (option leak_slot_units = 1)."""
+        count = self._last_n - first if count is None else count
+        u = np.zeros(count, dtype=np.uint32)
+        st = self._L.pc_hip_leak_slot_units(self._h, int(first), int(count), u.ctypes.data_as(C.POINTER(C.c_uint32)))
+        if st != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_leak_slot_units", st)
+        return u
+
     def transmission(self, seed, slot0, n_slots, max_attempts=1 << 20, keep_images=False, leak_calc=False):
         """run + wait + totals (+ images, + leak events) in one call."""
         self.run(seed, slot0, n_slots, max_attempts, keep_images, leak_calc)

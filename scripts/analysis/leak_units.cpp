@@ -20,7 +20,8 @@ extern "C" long long *leak_crit(void) { static long long r[6]; for (int k = 0; k
 extern "C" long long *leak_stats(void) { return pc_leak_stats; }
 
 extern "C" int leak_units(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int64_t n_slots, int max_depth,
-                          int64_t *per_slot /* [n_slots][6]: march, wall step, probe, other units, attempts, deepest level */)
+                          int64_t *per_slot /* [n_slots][8]: march, wall step, probe, other units, attempts, deepest level, units of the longest attempt,
+                                                  reflections + 1 summed over the attempts of the PLAIN trace of the same slot */)
 {
 	pc_host_tables t; std::string err;
 	if (pc_build_tables(p, t, err)) return 1;
@@ -43,8 +44,8 @@ extern "C" int leak_units(const pc_hip_problem *p, uint64_t seed, int64_t slot0,
 		cx.stack_overflow = 0;
 #pragma omp for schedule(dynamic, 16)
 		for (int64_t j = 0; j < n_slots; j++) {
-			int64_t *o = per_slot + 6*j;
-			memset(o, 0, 6*sizeof(int64_t));
+			int64_t *o = per_slot + 10*j;
+			memset(o, 0, 10*sizeof(int64_t));
 			for (uint32_t attempt = 0; attempt < (1u << 20); attempt++) {
 				pc_start s;
 				if (Pm.generic_src) pc_sample_photon<true>(Pm, seed, (uint64_t)(slot0 + j), attempt, s);
@@ -83,12 +84,27 @@ extern "C" int leak_units(const pc_hip_problem *p, uint64_t seed, int64_t slot0,
 				{
 					const long long crit = std::max(own[0], kid[0]);
 					if (att_units > crit_best[0]) { crit_best[0] = att_units; crit_best[1] = crit; }
+					if (att_units > o[6]) o[6] = att_units;
 					__atomic_fetch_add(&crit_sum[0], att_units, __ATOMIC_RELAXED);
 					__atomic_fetch_add(&crit_sum[1], crit, __ATOMIC_RELAXED);
 					if (att_units > 5000) { __atomic_fetch_add(&crit_sum[2], att_units, __ATOMIC_RELAXED); __atomic_fetch_add(&crit_sum[3], crit, __ATOMIC_RELAXED); }
 				}
 				o[4]++;
 				if (L.rc == 1 && pc_in_exit_window(Pm, ph)) break;
+			}
+			/* what a plain run (leak_calc=false) of the same slot sees: reflections of every attempt up to the transmitted one */
+			for (uint32_t attempt = 0; attempt < (1u << 20); attempt++) {
+				pc_start s;
+				if (Pm.generic_src) pc_sample_photon<true>(Pm, seed, (uint64_t)(slot0 + j), attempt, s);
+				else pc_sample_photon<false>(Pm, seed, (uint64_t)(slot0 + j), attempt, s);
+				pc_photon<1> q;
+				q.wmem = nullptr; q.wstride = 1;
+				int st = pc_launch_init(T, Pm, q, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez);
+				while (st != PC_ST_DONE) st = (st == PC_ST_MARCH) ? pc_march_step(T, Pm, q) : pc_event(T, Pm, t.ec.data(), q);
+				o[7] += q.irefl + 1;
+				if (q.rc == 2) o[8]++;
+				o[9]++;
+				if (q.rc == 1 && pc_in_exit_window(Pm, q)) break;
 			}
 		}
 	}

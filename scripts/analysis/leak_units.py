@@ -23,7 +23,7 @@ prof = capi.Profile(capi.Profile.ELLIPSOIDAL, 9., 0.2065, 0.0585, 0.00035, 9.915
 z, cap, ext = prof.get_z(), prof.get_cap(), prof.get_ext()
 a, s, _ = optical_constants([8, 14], [0.53, 0.47], 2.23, [10.0])
 prob = polycap_amd.Problem(z, cap, ext, 0.0, 200000, 2.23, [10.0], a, s, 2000.0, 0.2065, 0.2065, -1.0, 0.0, 0.0, 0.0, 0.5)
-out = np.zeros((n, 6), dtype=np.int64)
+out = np.zeros((n, 10), dtype=np.int64)
 L.leak_units.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
 rc = L.leak_units(C.byref(prob.s), 20000, 0, n, 532, out.ctypes.data)
 assert rc == 0
@@ -46,3 +46,28 @@ L.leak_crit.restype = C.POINTER(C.c_longlong * 6)
 cr = list(L.leak_crit().contents)
 print("critical path of an attempt if every leaked fraction had a lane of its own from its spawn: all attempts %.3g of %.3g units (%.2f);"
       " attempts above 5000 units %.3g of %.3g (%.2f); the longest attempt %d of %d" % (cr[1], cr[0], cr[1] / max(1, cr[0]), cr[3], cr[2], cr[3] / max(1, cr[2]), cr[5], cr[4]))
+# would handing out the slots heaviest first (by what a plain run of the same slots sees) shorten a launch?  List scheduling of
+# the slots' units on P lanes (every lane takes the next slot when it is done), in slot order against by descending predictor
+import heapq
+pred = out[:, 7].astype(float)
+print("plain-run predictor (reflections + 1 over a slot's attempts) against the slot's units: correlation %.3f; against its longest attempt %.3f"
+      % (np.corrcoef(pred, tot)[0, 1], np.corrcoef(pred, out[:, 6])[0, 1]))
+for P in (n // 4, n // 8):
+    res = []
+    for order in (np.arange(n), np.argsort(-pred, kind="stable"), np.argsort(-tot, kind="stable")):
+        h = [0] * P
+        for j in order:
+            heapq.heappush(h, heapq.heappop(h) + int(tot[j]))
+        res.append(max(h))
+    print("%d lanes for %d slots: makespan in units, slot order %d, heaviest first by the predictor %d, by the true units %d (mean load %d)"
+          % (P, n, res[0], res[1], res[2], tot.sum() // P))
+# a better predictor?  least squares of the units on (reflections, attempts that hit the glass at the entrance, attempts)
+X = np.stack([out[:, 7] - out[:, 9], out[:, 8], out[:, 9] - out[:, 8]], axis=1).astype(float)
+coef, *_ = np.linalg.lstsq(X, tot.astype(float), rcond=None)
+fit = X @ coef
+k = max(1, n // 400)
+top_true = set(np.argsort(-tot)[:k])
+for name, p_ in (("reflections + 1 per attempt", pred), ("fit %.1f * reflections + %.0f * attempts into the glass + %.0f * other attempts" % tuple(coef), fit)):
+    top_p = set(np.argsort(-p_)[:k])
+    print("%s: correlation %.3f; of the %d heaviest slots (0.25 %%) it finds %d; the heaviest slot it misses has %d units"
+          % (name, np.corrcoef(p_, tot)[0, 1], k, len(top_true & top_p), max([tot[j] for j in top_true - top_p] + [0])))

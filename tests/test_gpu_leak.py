@@ -205,6 +205,46 @@ def test_driver_with_leaks_is_event_for_event_the_host_compile(pa, oracle, optic
     assert n_events > 20000
 
 
+def test_order_of_the_slots_does_not_change_a_leak_run(pa, oracle, optic, leaks):
+    """Leak runs hand out their slots heaviest first (predicted by a plain pre-pass of the same slots) and give the heaviest ones
+    lanes of their own (pc_leak_kargs::order): totals, exit weights and every event of (a) a caller's arbitrary order with a heavy
+    tier on a small run and (b) the automatic order on a run large enough for it equal those of the same run in slot order."""
+    amu, scatf = constants(leaks, 10)
+    src = (2000., 0.2065, 0.2065, -1., 0., 0., 0., 0.5)
+    prob = problem(pa, optic, [10.0], [amu], [scatf], source=src)
+
+    def same(x, y):
+        assert np.array_equal(x["counters"], y["counters"]) and np.array_equal(x["sum_weights"], y["sum_weights"])
+        assert np.array_equal(x["ext"], y["ext"]) and np.array_equal(x["int"], y["int"])
+
+    with pa.TraceContext(prob) as ctx:
+        n = 6000
+        ctx.set_option("leak_order", 0)
+        ref = ctx.transmission(20000, 0, n, keep_images=True, leak_calc=True)
+        wref = ctx.images()["exit_weights"].copy()
+        rng = np.random.default_rng(5)
+        for n_heavy, lanes_, every in ((0, 1, 1), (40, 1, 1), (300, 2, 3)):
+            ctx.set_option("leak_heavy_lanes", lanes_)
+            ctx.set_option("leak_heavy_every", every)
+            ctx.leak_set_order(rng.permutation(n), n_heavy)
+            got = ctx.transmission(20000, 0, n, keep_images=True, leak_calc=True)
+            same(got, ref)
+            assert np.array_equal(ctx.images()["exit_weights"], wref)
+        with pytest.raises(pa.HipError):
+            ctx.leak_set_order(np.zeros(n, dtype=np.uint32), 0)           # not a permutation
+        ctx.leak_set_order(np.zeros(0, dtype=np.uint32), 0)               # back to the context's own choice
+        ctx.set_option("leak_heavy_lanes", 1)
+        ctx.set_option("leak_heavy_every", 1)
+        n = 200_000
+        plain = ctx.transmission(7, 0, n, leak_calc=True)
+        ctx.set_option("leak_order", 1)
+        ctx.set_option("leak_slot_units", 1)
+        ordered = ctx.transmission(7, 0, n, leak_calc=True)
+        same(ordered, plain)
+        units = ctx.leak_slot_units(0, n)
+        assert units.min() > 0 and units.max() > 20 * units.mean() / 4      # every slot traced; a heavy tail exists
+
+
 @pytest.mark.parametrize("binding", ["ctypes", "cython"])
 def test_public_api_with_leaks(pa, leaks, known, binding, monkeypatch):
     """The reference's Python test of the leak path (tests/python.py:147-201: one 40 keV photon, two extleak and three
