@@ -99,7 +99,7 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
  *   "slot_ids"         compact runs also record which slot sits at which position (pc_hip_transmission_slot_ids)
  *   "leak_order"       leak_calc source runs with two to five slots per lane hand out their slots heaviest first, predicted by
  *                      a plain pre-pass of the same slots, the heaviest n/400 to lanes of their own (default 1; 0 = slot order)
- *   "leak_heavy_lanes", "leak_heavy_every", "leak_heavy_company", "leak_park_units"   tuning of that (defaults 1, 1, 0, 0)
+ *   "leak_heavy_lanes", "leak_heavy_every"   which lanes the heaviest slots go to: lanes 0 .. n-1 of every m-th wave (defaults 1, 1)
  *   "leak_slot_units"  leak_calc source runs keep the units of work per slot (pc_hip_leak_slot_units)
  *   "batch_reflections" many-energy source runs: sweep a photon's weights once per four reflections (default 1)
  *   "fetch_threads"    host threads of the staging fallback of the image fetch (0 = min(16, cores))

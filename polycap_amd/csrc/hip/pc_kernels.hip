@@ -1173,8 +1173,7 @@ struct pc_hip_ctx {
 	unsigned int *d_work_est = nullptr; long long work_est_n = 0, leak_order_cap = 0;
 	int leak_ev0_done = 0;                 /* ev0 of the run in flight was recorded before its pre-pass */
 	long long leak_order_n = 0, leak_n_heavy = 0;
-	int leak_heavy_lanes = 1, leak_heavy_every = 1, leak_heavy_company = 0;
-	long long leak_park_units = 0;
+	int leak_heavy_lanes = 1, leak_heavy_every = 1;
 	int leak_slot_units = 0;               /* option: keep the units of work per slot of leak runs (pc_hip_leak_slot_units) */
 	unsigned int *d_leak_slot_units = nullptr;
 	long long leak_slot_units_n = 0;
@@ -1526,8 +1525,6 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "leak_order") { ctx->leak_order = value != 0; }
 	else if (n == "leak_slot_units") { ctx->leak_slot_units = value != 0; }
 	else if (n == "leak_heavy_lanes") { if (value < 0 || value > PC_WAVE) return pc_fail(PC_HIP_ERR_INVALID, "leak_heavy_lanes must be in 0..64"); ctx->leak_heavy_lanes = (int)value; }
-	else if (n == "leak_park_units") { if (value < 0) return pc_fail(PC_HIP_ERR_INVALID, "leak_park_units must be >= 0"); ctx->leak_park_units = (long long)value; }
-	else if (n == "leak_heavy_company") { if (value < 0 || value > PC_WAVE) return pc_fail(PC_HIP_ERR_INVALID, "leak_heavy_company must be in 0..64"); ctx->leak_heavy_company = (int)value; }
 	else if (n == "leak_heavy_every") { if (value < 0) return pc_fail(PC_HIP_ERR_INVALID, "leak_heavy_every must be >= 0"); ctx->leak_heavy_every = (int)value; }
 	else if (n == "leak_capacity") { if (value < 0) return pc_fail(PC_HIP_ERR_INVALID, "leak_capacity must be >= 0"); ctx->leak_capacity = (long long)value; }
 	else return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_set_option: unknown option " + n);

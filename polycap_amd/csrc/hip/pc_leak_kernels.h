@@ -43,8 +43,6 @@ struct pc_leak_kargs {
 	const unsigned int *order;
 	long long n_heavy;
 	int heavy_lanes, heavy_every;
-	int heavy_company;             /* lanes of a heavy wave that may work on light slots beside its heavy lanes */
-	unsigned int park_units;       /* a lane whose slot has taken more units than this gets its wave to itself (0 = never) */
 	unsigned int *slot_units;      /* [n_slots] units of work spent on each slot (what the next run of the same slots is ordered by), or null */
 };
 
@@ -186,7 +184,7 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 			cls = 4;
 			if (mode == PC_LM_PARKED) mode = PC_LM_NEED;            /* parked beside the heavy lanes of its wave: look again */
 			/* lanes of this wave that are at work on a slot of the heavy tier and will still be after this pass */
-			const unsigned long long heavy_busy = __ballot((my_heavy || (lk.park_units && my_units > lk.park_units)) && (mode == PC_LM_RUN || (mode == PC_LM_NEED && launched)));
+			const unsigned long long heavy_busy = __ballot(my_heavy && (mode == PC_LM_RUN || (mode == PC_LM_NEED && launched)));
 			if (mode == PC_LM_NEED) {
 				int need_slot = 1;
 				if (launched) {
@@ -260,8 +258,8 @@ pc_leak_kernel(pc_kargs a, pc_leak_kargs lk)
 						if (heavy_lane) {
 							pos = (long long)atomicAdd(&lk.cursor[2], 1ull);
 							if (pos >= lk.n_heavy) pos = -1; else my_heavy = 1;
-						} else if ((heavy_busy & ~(1ull << lane)) != 0ull
-						           || (heavy_wave && (long long)__hip_atomic_load(&lk.cursor[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lk.n_heavy)) {
+						} else if (heavy_wave && ((heavy_busy & ~(1ull << lane)) != 0ull
+						           || (long long)__hip_atomic_load(&lk.cursor[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lk.n_heavy)) {
 							park = 1;                                    /* the heavy lanes of this wave have the wave to themselves */
 						}
 						if (pos < 0 && !park) {
@@ -408,12 +406,11 @@ static int pc_leak_enqueue(pc_hip_ctx *ctx, pc_kargs &a, long long n_items, long
 	lk.records = ctx->d_leak_records; lk.cursor = ctx->d_leak_cursor; lk.capacity = capacity;
 	lk.final_attempt = ctx->d_leak_attempts;
 	lk.timing = nullptr;
-	lk.order = nullptr; lk.n_heavy = 0; lk.heavy_lanes = 0; lk.heavy_every = 0; lk.heavy_company = 0; lk.park_units = 0; lk.slot_units = nullptr;
+	lk.order = nullptr; lk.n_heavy = 0; lk.heavy_lanes = 0; lk.heavy_every = 0; lk.slot_units = nullptr;
 	if (MODE != PC_MODE_EXPLICIT) {
 		if (ctx->d_leak_order && ctx->leak_order_n == n_items) {
 			lk.order = ctx->d_leak_order;
-			lk.heavy_lanes = ctx->leak_heavy_lanes; lk.heavy_every = ctx->leak_heavy_every; lk.heavy_company = ctx->leak_heavy_company;
-			lk.park_units = (unsigned int)ctx->leak_park_units;
+			lk.heavy_lanes = ctx->leak_heavy_lanes; lk.heavy_every = ctx->leak_heavy_every;
 			lk.n_heavy = (lk.heavy_lanes > 0 && lk.heavy_every > 0) ? std::min<long long>(ctx->leak_n_heavy, n_items) : 0;
 		}
 		if (ctx->leak_slot_units) {
