@@ -16,9 +16,13 @@ z, cap, ext = prof.get_z(), prof.get_cap(), prof.get_ext()
 a, s, _ = optical_constants([8, 14], [0.53, 0.47], 2.23, E)
 prob = polycap_amd.Problem(z, cap, ext, 0.0, 200000, 2.23, E, a, s, 2000.0, 0.2065, 0.2065, -1.0, 0.0, 0.0, 0.0, 0.5)
 with polycap_amd.TraceContext(prob) as ctx:
+    seed = 20000
     for k, v in [kv.split("=") for kv in sys.argv[3:]]:
-        ctx.set_option(k, int(v))
-    r = ctx.transmission(20000, 0, n, leak_calc=True)
+        if k == "seed":
+            seed = int(v)
+        else:
+            ctx.set_option(k, int(v))
+    r = ctx.transmission(seed, 0, n, leak_calc=True)
     st = ctx.phase_stats()
 print("nE=%d slots=%d kernel %.1f ms started %d ext %d int %d -> %.3g started photons/s; lanes/unit wall %.1f probe %.1f march %.1f; units %.3g %.3g %.3g"
       % (len(E), n, r["kernel_ms"], r["i_start"], len(r["ext"]), len(r["int"]), r["i_start"] / (r["kernel_ms"] * 1e-3),
