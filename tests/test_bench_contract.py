@@ -57,3 +57,23 @@ def test_host_cpu_description():
     import bench
     n, quota, model = bench.host_cpus()
     assert n >= 1 and (quota is None or quota > 0) and isinstance(model, str) and model
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    """profiles/r03/headline_bench.json is the line `python bench.py` printed on the MI355X box of the round's final evidence run:
+    the keys the driver reads, the two objects the tier asks for, and the extra legs DESIGN section 7 quotes."""
+    with open(os.path.join(ROOT, "profiles", "r03", "headline_bench.json")) as f:
+        d = json.load(f)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] > 0
+    assert r["kernel_ms"] <= d["ms_per_step"]          # a step is the kernel + totals + reduce
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    for leg in ("wall_incl_copyback", "sweep_291", "ellip_l9_rough", "leak_262144", "parity_fixture"):
+        assert leg in d, leg
+    assert d["parity_fixture"]["within_tolerance"] and d["parity_fixture"]["eff_rel_delta_pooled"] <= 1e-4
+    assert d["leak_262144"]["n_exit"] == 262144 and d["leak_262144"]["started_photons_per_s"] > 2e6
