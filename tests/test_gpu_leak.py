@@ -245,6 +245,35 @@ def test_order_of_the_slots_does_not_change_a_leak_run(pa, oracle, optic, leaks)
         assert units.min() > 0 and units.max() > 20 * units.mean() / 4      # every slot traced; a heavy tail exists
 
 
+def test_leak_driver_totals_against_the_oracle_fixture(pa, oracle, optic, leaks):
+    """tests/golden/oracle_leak_totals.json (scripts/make_oracle_leak_totals.py): the CPU oracle's leak driver -- the reference's
+    literal algorithm -- on 8000 exit-photon slots of the leak bench's workload.  Identical photon streams; the trajectories
+    are chaotic, so the kernel agrees statistically, not event by event: started photons, efficiency, numbers
+    and summed weights of both kinds of leak event within a few times their noise (bounds = about twice what was measured)."""
+    import json
+    import os
+    from tests.conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "oracle_leak_totals.json")) as f:
+        fx = json.load(f)
+    amu, scatf = constants(leaks, 10)
+    prob = problem(pa, optic, [fx["energy_keV"]], [amu], [scatf], source=tuple(fx["source"]))
+    n = sum(b["n"] for b in fx["blocks"])
+    with pa.TraceContext(prob) as ctx:
+        g = ctx.transmission(fx["seed"], 0, n, leak_calc=True)
+    o_cnt = np.sum([b["counters"] for b in fx["blocks"]], axis=0)
+    o_start = o_cnt[0] + o_cnt[1] + o_cnt[2]
+    g_start = g["i_start"]
+    o_eff = sum(b["sum_weight"] for b in fx["blocks"]) / o_start
+    assert g["i_exit"] == n == o_cnt[0]
+    assert abs(g_start - o_start) <= 3. * np.sqrt(o_start)
+    assert abs(g["efficiencies"][0] - o_eff) <= 1.0 / np.sqrt(o_start) * o_eff           # measured: 0.29 / sqrt(N)
+    for kind, key in (("ext", "n_ext"), ("int", "n_int")):
+        o_n = sum(b[key] for b in fx["blocks"])
+        o_w = sum(b[kind + "_weight"] for b in fx["blocks"])
+        assert abs(len(g[kind]) - o_n) <= 0.015 * o_n + 3. * np.sqrt(o_n)                   # measured: -0.6 %, +0.1 %
+        assert abs(g[kind][:, 12].sum() - o_w) <= 0.03 * o_w + 0.01                          # measured: -1.5 %, +0.6 %
+
+
 @pytest.mark.parametrize("binding", ["ctypes", "cython"])
 def test_public_api_with_leaks(pa, leaks, known, binding, monkeypatch):
     """The reference's Python test of the leak path (tests/python.py:147-201: one 40 keV photon, two extleak and three
