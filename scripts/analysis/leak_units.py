@@ -71,3 +71,8 @@ for name, p_ in (("reflections + 1 per attempt", pred), ("fit %.1f * reflections
     top_p = set(np.argsort(-p_)[:k])
     print("%s: correlation %.3f; of the %d heaviest slots (0.25 %%) it finds %d; the heaviest slot it misses has %d units"
           % (name, np.corrcoef(p_, tot)[0, 1], k, len(top_true & top_p), max([tot[j] for j in top_true - top_p] + [0])))
+miss = sorted(top_true - set(np.argsort(-pred)[:k]), key=lambda j: -tot[j])[:12]
+rank = np.empty(n, dtype=np.int64); rank[np.argsort(-pred)] = np.arange(n)
+print("the heaviest slots the plain predictor misses: units, longest attempt, attempts, deepest level, predictor, its rank")
+for j in miss:
+    print("  %7d %7d %3d %3d %6d %6d" % (tot[j], out[j, 6], out[j, 4], out[j, 5], out[j, 7], rank[j]))
