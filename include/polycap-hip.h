@@ -101,7 +101,12 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
  *                      a plain pre-pass of the same slots, the heaviest n/400 to lanes of their own (default 1; 0 = slot order)
  *   "leak_heavy_lanes", "leak_heavy_every"   which lanes the heaviest slots go to: lanes 0 .. n-1 of every m-th wave (defaults 1, 1)
  *   "leak_slot_units"  leak_calc source runs keep the units of work per slot (pc_hip_leak_slot_units)
- *   "batch_reflections" many-energy source runs: sweep a photon's weights once per four reflections (default 1)
+ *   "batch_reflections" source runs with more than 32 energies: 1 (default) reflections are logged (24 B each) and a photon's
+ *                      weights swept once per log, 2 round 3's kernel (four reflections wait in LDS per sweep), 0 every
+ *                      reflection sweeps the weights at once
+ *   "log_cap"          reflections per log of the logging kernel (default 64, 1..255)
+ *   "sweep_skip"       histogram-only runs of the logging kernel stop multiplying a weight once it is below 2^-64 (it adds
+ *                      nothing to the exact sums any more; default 1)
  *   "fetch_threads"    host threads of the staging fallback of the image fetch (0 = min(16, cores))
  *   leak runs: "leak_max_depth" (stack frames per lane = walls one photon may cross), "leak_stack_mb" (HBM for those
  *                      stacks), "leak_capacity" (leak record buffer, 0 = automatic; a run that outgrows it is repeated). */
@@ -203,8 +208,15 @@ POLYCAP_EXTERN int pc_hip_group_totals(pc_hip_group *group, int reduce, double *
 POLYCAP_EXTERN int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6]);
 /* Which kernel traced the last source run: 0 one photon per lane (pc_trace_kernel), 1 LDS photon pool (option "pool"),
  * 2 launching wave per workgroup (option "producer"; by default chosen when the photons of the context's last run made at
- * least 4 segment visits (reflections, mostly; absorbed photons included) per launch -- a first run of 2e6 slots or more is preceded by a 32768-slot probe).  -1: none yet. */
+ * least 4 segment visits (reflections, mostly; absorbed photons included) per launch -- a first run of 2e6 slots or more is preceded by a 32768-slot probe),
+ * 3 one wave per photon (experiment builds only), 4 logged reflections (pc_trace_log_kernel: source runs with more than 32
+ * energies, option "batch_reflections" 1).  -1: none yet. */
 POLYCAP_EXTERN int pc_hip_last_kernel(pc_hip_ctx *ctx);
+/* The weight sweeps of the last run when pc_trace_log_kernel traced it: stats = {wave-level passes over 64 (photon, energy)
+ * pairs, wave-level (pass, reflection) iterations}; *ct_tame (optional) = the grazing cosine above which the host certified
+ * every energy's reflectivity inside [0, 1 - 1e-11] (-1: no log run yet); proxies (optional) = the one or two energy indices
+ * every lane follows itself (-1: none) */
+POLYCAP_EXTERN int pc_hip_sweep_stats(pc_hip_ctx *ctx, int64_t stats[2], double *ct_tame, int proxies[2]);
 
 /* efficiency formula of src/polycap-source.c:1066-1076 from (summed) totals */
 POLYCAP_EXTERN void pc_hip_efficiencies(size_t n_energies, const double *sum_weights, const int64_t counters[6], double *efficiencies);

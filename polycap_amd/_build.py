@@ -21,13 +21,19 @@ LIB = os.path.join(LIBDIR, "libpolycap.so")
 HOST_SRCS = ["pc_error.c", "pc_rng.c", "pc_profile.c", "pc_description.c", "pc_optconst.c",
              "pc_photon.c", "pc_source.c", "pc_transeff.c", "pc_hdf5.c"]
 HIP_SRCS = ["pc_kernels.hip"]
-HIP_DEPS = ["pc_device.h", "pc_problem.h", "pc_leak.h", "pc_leak_kernels.h", "pc_pool_kernel.h", "pc_producer_kernel.h", "pc_wave_kernel.h", "pc_group.h"]
+HIP_DEPS = ["pc_device.h", "pc_problem.h", "pc_leak.h", "pc_leak_kernels.h", "pc_pool_kernel.h", "pc_producer_kernel.h", "pc_wave_kernel.h", "pc_sweep_kernel.h", "pc_group.h"]
 
 CFLAGS = ["-std=c11", "-O2", "-fPIC", "-Wall", "-Wextra", "-fvisibility=hidden", "-I" + INC, "-I" + HOST]
 # -ffp-contract=off: fused multiply-adds appear only where pc_device.h writes fma() explicitly, so the device
 # arithmetic is the same IEEE operation sequence on gfx950 and in the host-compiled test emulation
 HIPFLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
             "-I" + INC, "-I" + HIPD]
+if os.environ.get("POLYCAP_EXPERIMENTS"):      # A/B scripts of kernels that are not part of the product (pc_wave_kernel.h)
+    HIPFLAGS.append("-DPC_EXPERIMENTS")
+# what the library exports: the reference's C API, the thin HIP C-ABI and the few host helpers the Python layer binds; the
+# kernels' host stubs and the C++ runtime's weak instantiations stay local (reference: meson.build:85-100, default-hidden
+# visibility with POLYCAP_EXTERN only)
+VERSION_SCRIPT = os.path.join(HERE, "csrc", "libpolycap.map")
 
 
 def _newer(target, deps):
@@ -60,8 +66,9 @@ def build(force=False, verbose=False):
         if force or _newer(obj, deps):
             _run(["hipcc"] + HIPFLAGS + ["-c", src, "-o", obj], verbose)
         objs.append(obj)
-    if force or _newer(LIB, objs):
-        _run(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-lm", "-lpthread"], verbose)
+    if force or _newer(LIB, objs + [VERSION_SCRIPT]):
+        _run(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-Wl,--version-script=" + VERSION_SCRIPT, "-o", LIB] + objs +
+             ["-ldl", "-lm", "-lpthread"], verbose)
     build_cli(force=force, verbose=verbose)
     build_cython(force=force, verbose=verbose)
     return LIB

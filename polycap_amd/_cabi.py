@@ -150,6 +150,8 @@ def lib():
     L.pc_hip_phase_stats.restype = C.c_int
     L.pc_hip_last_kernel.argtypes = [C.c_void_p]
     L.pc_hip_last_kernel.restype = C.c_int
+    L.pc_hip_sweep_stats.argtypes = [C.c_void_p, c_int64_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.pc_hip_sweep_stats.restype = C.c_int
     L.pc_hip_device_synchronize.argtypes = [C.c_void_p]
     L.pc_hip_device_synchronize.restype = C.c_int
     L.pc_hip_group_create.argtypes = [P(ProblemS), C.c_int, P(C.c_int), P(C.c_void_p)]

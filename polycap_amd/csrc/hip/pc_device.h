@@ -44,6 +44,9 @@ struct pc_energy_const {
 	double ninv2_re, ninv2_im;
 	double rough_c;
 	double valid;   /* 0 -> polycap_refl_polar would reject its arguments (returns -1) */
+	/* FORM 3 (pc_fresnel3: the weight sweeps of runs whose weights live in memory): n^2 = n2_re + i n2_im, d2 = 1 - n2_re
+	 * = alfa (2 - alfa) + beta^2 without the cancellation, zi2 = max(n2_im^2, 2^-200), rough_k2 = rough_c^2 */
+	double d2, n2_re, n2_im, zi2, rough_k2;
 };
 
 struct pc_params {
@@ -53,6 +56,8 @@ struct pc_params {
 	int literal;        /* 1: no certificate, every segment takes the full quadratic */
 	int uniform_illum;  /* src_sigx < 0 || src_sigy < 0 */
 	int generic_src;    /* src_x != src_y: elliptical source, libm sampling path */
+	int form3;          /* the run's weights live in memory (more than 8 energies, or several on a profile of more than 1024 points):
+	                     * its reflections evaluate the Fresnel factor in FORM 3 (pc_fresnel3) */
 	double n_shells;
 	double hexscale;    /* 2*cos(pi/6)*(n_shells+1) */
 	double inv_hexscale; /* 1/hexscale, for certificates (outcomes divide by hexscale like the reference) */
@@ -750,17 +755,24 @@ PC_HD int pc_reflect_energy(const pc_energy_const &ec, const pc_refl_geom &g, do
 	return single ? pc_reflect_energy_f<0>(ec, g, w) : pc_reflect_energy_f<1>(ec, g, w);
 }
 
-/* ------------------------------------------------------------------ FORM 2: the sweeps of the any-n_energies kernel
- * The same reflectivity as FORM 1 (everything carried multiplied by 2t), written for the weight sweeps of runs whose weights
- * live in memory (more than 8 energies): there the Fresnel arithmetic IS the kernel (75 % of its instructions), and two
- * correctly rounded fp64 square roots and a division are ~45 of its ~100 instructions per energy and reflection.  On the
- * device the two roots come from v_rsq_f64 and the quotient from v_rcp_f64 (2^-24, measured: scripts/analysis/fp64_rates.hip)
- * with one Newton step each (2^-48 ~ 4e-15 relative, no range scaling: the arguments are |w|^2 and 2(|w| + |Re w|) with
- * |w| >= |Im(1/n^2)| sin^2, far from the ends of the exponent range) -- 14 instructions instead of 45.  The weights then
- * differ from FORM 0/1 and from the host compile by a few 1e-15 per reflection; the trajectory does not depend on them (only
- * the rare "no weight >= 1e-4 left" decision does), so the kernel stays photon-for-photon the host compile up to those
- * decisions.  The host compile evaluates the same expressions with IEEE sqrt and division.  Callers guarantee ec.valid != 0
- * (runs with an invalid energy keep FORM 1). */
+/* ------------------------------------------------------------------ FORM 3: the sweeps of the any-n_energies kernels
+ * Runs whose weights live in memory (more than 8 energies, or several on a long profile) spend their time in the Fresnel
+ * factor: 291 energies x 21 reflections per started photon.  FORM 3 is the same reflectivity (polycap_refl_polar,
+ * src/polycap-capil.c:497-545) written for that loop:
+ *   - g = n csq = sqrt(n^2 - sin^2) is formed directly: z = g^2 = (cos^2 - d2) + i n2_im with d2 = 1 - Re n^2 kept as a
+ *     constant of its own (no 1 - (1 + 2 delta)(1 - cos^2): the reference's cancellation is not reproduced, the result is
+ *     closer to the exact value than the reference's own), Im z is a constant >= 0, so no sign handling and |z|^2 is one
+ *     fma; the complex product n * csq of FORMs 0-2 disappears;
+ *   - everything is carried multiplied by S = 2 max(Re g, Im g) = sqrt(2Q), Q = |z| + |Re z|: S g = (Q, Im z) or (Im z, Q);
+ *   - r_s = (cos - g)/(cos + g), r_p = (g - n^2 cos)/(g + n^2 cos) (:507-515 multiplied by n);
+ *   - the polarisation fractions fs = es2/sd2, fp = ep2/sd2 come per reflection (two IEEE divisions in the lane that
+ *     reflects), so rtot = (fs Ns Dp + fp Np Ds)/(Ds Dp): one reciprocal;
+ *   - on the device the two roots come from v_rsq_f64 and the quotient from v_rcp_f64 (2^-24, scripts/analysis/fp64_rates.hip)
+ *     with one Newton step each (~4e-15 relative); |z|^2 >= zi2 >= 2^-200 keeps them finite.  The host compile evaluates
+ *     the same expressions with IEEE sqrt and division.
+ * 46 instructions per energy and reflection (FORM 2, round 3: 57).  The weights differ from FORMs 0/1 by the reference's own
+ * rounding noise (~1e-10 relative near the critical angle, where 1 - sin^2/n^2 cancels); the trajectory does not depend on
+ * them.  Callers guarantee ec.valid != 0 (runs with an invalid energy keep FORM 1). */
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PC_FAST_MATH_DEVICE 1
 #else
@@ -817,38 +829,47 @@ PC_HD double pc_exp_neg_fast(double x)
 #endif
 }
 
-/* per-energy constants of FORM 2: n = n_re + i n_im, (1/n)^2 = a_re + i a_im, rough_c; reflection geometry ct = cos(theta)
- * (>= 0), st2 = sin^2, es2, ep2, sd2 as in pc_refl_geom.  Returns the factor rtot (* r_rough if ROUGH) the weight is multiplied
- * by; rtot itself goes to `rt` for the caller's range test (the reference rejects rtot < 0 or > 1, :633-637). */
-template <bool ROUGH>
-PC_HD double pc_fresnel_fast(double n_re, double n_im, double a_re, double a_im, double rough_c,
-                             double ct, double st2, double es2, double ep2, double sd2, double &rt)
+/* what FORM 3 takes from a reflection's geometry: c2 = cos^2, fs = (E.s)^2 / |n x d|^2, fp = 1 - fs as the reference
+ * forms it (frac_p from the p component: ep2 / sd2) */
+PC_HD void pc_refl_geom3(const pc_refl_geom &g, double &c2, double &fs, double &fp)
 {
-	const double wr = fma(-a_re, st2, 1.0);
-	const double wi = -a_im*st2;
-	/* |w|^2, floored far below anything a physical 1/n^2 produces (w == 0 needs Im n == 0 and the exact critical angle): keeps
-	 * the reciprocal square roots finite; the result there is the limit R = 1 to rounding */
-	const double mag2 = fmax(fma(wr, wr, wi*wi), 6.223015277861142e-61 /* 2^-200 */);
-	const double mag = pc_sqrt_fast(mag2);
-	const double q2 = mag + fabs(wr);                        /* 2 t^2 */
-	const double sc = pc_sqrt_fast(q2 + q2);                 /* 2 t */
-	const double cts = ct*sc;
-	const double awi = fabs(wi);
-	const double csr = (wr >= 0.) ? q2 : awi;
-	const double csi = copysign((wr >= 0.) ? awi : q2, wi);
-	const double tr = fma(n_re, csr, -n_im*csi);
-	const double ti = fma(n_re, csi, n_im*csr);
-	const double nr = cts - tr, dr = cts + tr;
-	const double ti2 = ti*ti;
-	const double Ns = fma(nr, nr, ti2), Ds = fma(dr, dr, ti2);
-	const double ur = n_re*cts, ui = n_im*cts;
-	const double pr = csr - ur, pi_ = csi - ui, er = csr + ur, ei = csi + ui;
+	c2 = g.alfa*g.alfa;
+	fs = g.es2/g.sd2;
+	fp = g.ep2/g.sd2;
+}
+
+/* rtot of one energy: d2, n2r, n2i, zi2 from pc_energy_const; c = cos(theta) (>= 0), c2, fs, fp from pc_refl_geom3 */
+PC_HD double pc_fresnel3(double d2, double n2r, double n2i, double zi2, double c, double c2, double fs, double fp)
+{
+	const double zr = c2 - d2;
+	const double mag = pc_sqrt_fast(fma(zr, zr, zi2));
+	const double Q = mag + fabs(zr);
+	const double S = pc_sqrt_fast(Q + Q);
+	const double cS = c*S;
+	const bool up = zr >= 0.;
+	const double Gr = up ? Q : n2i, Gi = up ? n2i : Q;
+	const double nr = cS - Gr, dr = cS + Gr;
+	const double Gi2 = Gi*Gi;
+	const double Ns = fma(nr, nr, Gi2), Ds = fma(dr, dr, Gi2);
+	const double A = n2r*cS, B = n2i*cS;
+	const double pr = A - Gr, pi_ = B - Gi, er = A + Gr, ei = B + Gi;
 	const double Np = fma(pr, pr, pi_*pi_), Dp = fma(er, er, ei*ei);
-	const double rtot = pc_div_fast(fma(es2*Ns, Dp, ep2*Np*Ds), sd2*Ds*Dp);
-	rt = rtot;
-	if (!ROUGH) return rtot;
-	const double c1 = rough_c*ct;
-	return rtot*pc_exp_neg_fast(-c1*c1);
+	return pc_div_fast(fma(fs*Ns, Dp, (fp*Np)*Ds), Ds*Dp);
+}
+
+/* one energy of one reflection in FORM 3, the roughness factor per reflection as the reference applies it (:626-627).
+ * Same return values as pc_reflect_energy_f. */
+PC_HD int pc_reflect_energy3(const pc_energy_const &ec, double c, double c2, double fs, double fp, double &w)
+{
+	const double rt = pc_fresnel3(ec.d2, ec.n2_re, ec.n2_im, ec.zi2, c, c2, fs, fp);
+	if (rt < 0. || rt > 1.) return -1;                          /* src/polycap-capil.c:633-637 */
+	double f = rt;
+	if (ec.rough_c != 0.) {
+		const double c1 = ec.rough_c*c;
+		f = rt*pc_exp_neg_fast(-c1*c1);
+	}
+	w = w*f;
+	return (w >= 1.e-4) ? 1 : 0;
 }
 
 /* whole reflection for one lane: geometry, all energies in order (stopping at the first error like the reference),
@@ -861,6 +882,25 @@ PC_HD int pc_reflect(const pc_params &Pm, const pc_energy_const *EC, pc_photon<N
 	if (pc_reflect_geom(ph, nx, ny, nz, g) < 0) return -1;
 	int keep = 0;
 	const int ne = (NE > 0) ? NE : Pm.n_energies;
+	if (NE == 0 && Pm.form3) {
+		/* what the kernels with weights in memory evaluate (serial here: the host compile of the tests) */
+		bool all_valid = true;
+		for (int e = 0; e < ne; e++) all_valid = all_valid && EC[e].valid != 0.;
+		if (all_valid) {
+			double c2, fs, fp;
+			pc_refl_geom3(g, c2, fs, fp);
+			for (int e = 0; e < ne; e++) {
+				double we = ph.wset ? ph.wmem[e*ph.wstride] : 1.0;
+				const int r = pc_reflect_energy3(EC[e], g.alfa, c2, fs, fp, we);
+				if (r < 0) return -1;
+				ph.wmem[e*ph.wstride] = we;
+				keep |= r;
+			}
+			ph.wset = 1;
+			ph.ex = fabs(ph.ex); ph.ey = fabs(ph.ey); ph.ez = fabs(ph.ez);
+			return keep;
+		}
+	}
 	for (int e = 0; e < ne; e++) {
 		double we = (NE > 0) ? ph.w[NE > 0 ? e : 0] : (ph.wset ? ph.wmem[e*ph.wstride] : 1.0);
 		int r = (NE == 1) ? pc_reflect_energy_f<0>(EC[e], g, we) : ((NE > 1) ? pc_reflect_energy_f<1>(EC[e], g, we) : pc_reflect_energy(EC[e], g, we, ne == 1));

@@ -43,21 +43,6 @@
                                 * 3: 23.6 ms, 4: 23.4, 5: 23.9, 8: 24.1 (scripts/ab_build.sh, xos1 10 keV, 1e7 slots) */
 #endif
 #define PC_KE 5                /* energies per lane whose weights are in flight together in a cooperative sweep */
-#ifndef PC_KB
-#define PC_KB 4                /* reflections of a photon that wait for one sweep of its weights (batched many-energy kernel): 96 B of LDS
-                                * per lane.  With 8 waves per CU (512 lanes), xos1 291 energies 1e6 slots / ellip_l9 291 sig 5 A 5e5 / xos1 100
-                                * energies, kernel ms: 4: 42.3 / 28.7 / 18.3, 5: 38.9 / 27.9 / 16.8 (scripts/ab_ne3.sh); with 12 waves
-                                * (PC_BLOCK_BATCH 768) 4 is what fits next to the tables */
-#endif
-#ifndef PC_BLOCK_BATCH
-#define PC_BLOCK_BATCH 768     /* workgroup of the batched many-energy kernel (pc_trace_kernel<0, MODE, 1024, true>): 12 waves per CU, 3 per SIMD */
-#endif
-#ifndef PC_WAVES_BATCH
-#define PC_WAVES_BATCH 3       /* ... and the waves per SIMD its registers must leave room for (168 VGPRs) */
-#endif
-#ifndef PC_SWEEP_IL
-#define PC_SWEEP_IL 1          /* (photon, energy) items a lane has in flight together in the flat sweep of the many-energy kernel */
-#endif
 #ifndef PC_CHUNK
 #define PC_CHUNK 128           /* slots a wave takes from the global counter at a time */
 #endif
@@ -93,7 +78,7 @@ struct pc_kargs {
 	const pc_drdev *g_dr;         /* leak path: chord deviations of cap per start node */
 	unsigned int *work_est;       /* [n_slots] or null: reflections + 1 of every attempt, summed per slot (lane kernels, source runs) */
 	const pc_energy_const *ec;
-	const double *ec_soa;         /* the same constants field-major [6][n_energies]: coalesced loads in the cooperative sweeps */
+	const double *ec_soa;         /* the sweeps' constants field-major [7][n_energies] (FORM 3: d2, n2_re, n2_im, zi2, rough_c, valid, rough_k2) */
 	pc_params pm;
 	unsigned long long seed;
 	long long slot0, n_slots;
@@ -127,14 +112,20 @@ struct pc_kargs {
 	int new_threshold;
 	int lds_acc;                  /* NE == 0: accumulate weight sums in LDS (2*n_energies u64 of dynamic LDS) */
 	int lds_ec;                   /* NE == 0: per-energy constants staged in LDS behind the sums (6*n_energies doubles) */
-	int lds_pend;                 /* NE == 0, more than 32 energies: reflections wait in LDS (PC_KB x 3 doubles per lane, behind the
-	                               * constants) and a photon's weights are swept once per PC_KB reflections */
 	int sweep_rough;              /* NE == 0: some energy has a roughness factor (sig_rough != 0): the sweeps evaluate exp(-(c alfa)^2) */
 	int pool_event_min;           /* pool kernel: photons waiting for an EVENT phase that make it run before anything else */
 	int event_march;              /* pool kernel: march steps taken right after an EVENT phase, while the wave is still full of fresh flights */
 	int pool_refill;              /* pool kernel: lanes that must be free before a march burst tops itself up from the pool */
 	double *wscratch;             /* NE==0: n_energies * total_threads */
 	long long total_threads;
+	/* pc_trace_log_kernel (pc_sweep_kernel.h): many-energy source runs whose reflections are logged */
+	double *rlog;                 /* [total_threads][log_cap][3]: cos theta, fs, fp (pc_refl_geom3) of the lane's logged reflections */
+	int log_cap;                  /* reflections per log */
+	int stage_ps;                 /* photons of a wave swept per round: their logs are staged in LDS (stage_ps*log_cap*PCS_ENT doubles per wave) */
+	int n_proxy, proxy_e[2];      /* energies whose weights every lane carries itself (pc_sweep_certificate) */
+	int flush_min;                /* photons of a wave that wait for a sweep before one is run for them alone */
+	int sweep_skip;               /* histogram-only runs: a weight below 2^-64 is not multiplied any further */
+	double ct_tame;               /* a reflection with cos theta >= ct_tame has 0 <= rtot < 1 - 1e-11 at every energy of the run */
 	/* explicit-photon mode */
 	const double *in_start, *in_dir, *in_elecv;
 	int *out_rc;
@@ -240,17 +231,23 @@ __device__ __forceinline__ void pc_atomic_add128(unsigned long long *lohi, unsig
 	if (hi + carry) atomicAdd(&lohi[1], hi + carry);
 }
 
-/* one energy of one reflection in the sweeps of the any-n_energies kernel: FORM 2 of pc_device.h (hardware reciprocal
- * square root / reciprocal + one Newton step).  Same return values as pc_reflect_energy_f. */
-__device__ __forceinline__ int pc_reflect_energy_sweep(const pc_energy_const &ec, const pc_refl_geom &g, double &w, int rough)
+/* the six per-energy constants of the immediate sweeps, field-major in ec_soa / its LDS copy: d2, n2_re, n2_im, zi2, rough_c,
+ * valid (FORM 3, pc_device.h); the seventh field of ec_soa, rough_k2, is what pc_trace_log_kernel reads instead of rough_c */
+__device__ __forceinline__ pc_energy_const pc_ec_from_soa(const double *ecs, int ne, int e)
+{
+	pc_energy_const ec;
+	ec.n_re = ec.n_im = ec.ninv2_re = ec.ninv2_im = ec.rough_k2 = 0.;
+	ec.d2 = ecs[e]; ec.n2_re = ecs[ne + e]; ec.n2_im = ecs[2*ne + e]; ec.zi2 = ecs[3*ne + e];
+	ec.rough_c = ecs[4*ne + e]; ec.valid = ecs[5*ne + e];
+	return ec;
+}
+
+/* one energy of one reflection in the immediate sweeps of the any-n_energies kernel: FORM 3 of pc_device.h.  Same return
+ * values as pc_reflect_energy_f. */
+__device__ __forceinline__ int pc_reflect_energy_sweep(const pc_energy_const &ec, double c, double c2, double fs, double fp, double &w)
 {
 	if (ec.valid == 0.) return -1;
-	double rt;
-	const double f = rough ? pc_fresnel_fast<true>(ec.n_re, ec.n_im, ec.ninv2_re, ec.ninv2_im, ec.rough_c, g.alfa, g.st2, g.es2, g.ep2, g.sd2, rt)
-	                       : pc_fresnel_fast<false>(ec.n_re, ec.n_im, ec.ninv2_re, ec.ninv2_im, 0., g.alfa, g.st2, g.es2, g.ep2, g.sd2, rt);
-	if (rt < 0. || rt > 1.) return -1;                          /* src/polycap-capil.c:633-637 */
-	w = w*f;
-	return (w >= 1.e-4) ? 1 : 0;
+	return pc_reflect_energy3(ec, c, c2, fs, fp, w);
 }
 
 /* --------------------------------------------------------------------------- the trace kernel
@@ -260,34 +257,27 @@ __device__ __forceinline__ int pc_reflect_energy_sweep(const pc_energy_const &ec
  * source; PC_MODE_SRC_CIRCULAR / _GENERIC: photons are sampled from the source (circular / elliptical). */
 enum { PC_MODE_SRC_CIRCULAR = 0, PC_MODE_SRC_GENERIC = 1, PC_MODE_EXPLICIT = 2 };
 
-/* BATCH (NE == 0, source modes, profiles of up to 1024 points): the kernel of runs with more than 32 energies whose
- * reflections wait in LDS for the flat sweep (pc_kargs::lds_pend).  An instantiation of its own, without the immediate
- * sweeps: 171 instead of 237 VGPRs, so that three waves per SIMD fit (its sweep is bound by VALU issue and its trace phases
- * by latency: more waves help both), and with the two tables only the EVENT phase reads (hexd, idz) left in global memory
- * to make room in LDS for the reflections of 768 lanes. */
-template <int NE, int MODE, int PITCH, bool BATCH = false>
-__global__ void __launch_bounds__(BATCH ? PC_BLOCK_BATCH : PC_BLOCK, BATCH ? PC_WAVES_BATCH : (NE == 0 ? PC_MIN_WAVES_NE0 : PC_MIN_WAVES))
+/* Source runs with more than 32 energies have a kernel of their own: pc_trace_log_kernel (pc_sweep_kernel.h). */
+template <int NE, int MODE, int PITCH>
+__global__ void __launch_bounds__(PC_BLOCK, NE == 0 ? PC_MIN_WAVES_NE0 : PC_MIN_WAVES)
 pc_trace_kernel(pc_kargs a)
 {
 	constexpr bool EXPLICIT = (MODE == PC_MODE_EXPLICIT);
-	static_assert(!BATCH || (NE == 0 && MODE != PC_MODE_EXPLICIT), "the batched kernel serves many-energy source runs");
 	/* static LDS with a compile-time pitch: table reads become ds_read with immediate offsets */
-	__shared__ double lds[(BATCH ? 4 : 6)*PITCH];
+	__shared__ double lds[6*PITCH];
 	__shared__ pc_marg4 ldsg[PITCH];
 	/* NE == 0: per-workgroup exact weight sums, (lo, hi) per energy, when they fit (a.lds_acc); else global atomics */
 	extern __shared__ unsigned long long l_acc[];
 	const int npts = a.pm.nmax + 1;
 	double *l_z = lds, *l_cap = lds + PITCH, *l_zh = lds + 2*PITCH, *l_cap2 = lds + 3*PITCH;
-	double *l_hexd = BATCH ? nullptr : lds + 4*PITCH, *l_idz = BATCH ? nullptr : lds + 5*PITCH;
+	double *l_hexd = lds + 4*PITCH, *l_idz = lds + 5*PITCH;
 	for (int k = threadIdx.x; k < npts; k += blockDim.x) {
 		l_z[k] = a.g_z[k];
 		l_cap[k] = a.g_cap[k];
 		l_zh[k] = a.g_zh[k];
 		l_cap2[k] = a.g_cap2[k];
-		if (!BATCH) {
-			l_hexd[k] = a.g_hexd[k];
-			l_idz[k] = a.g_idz[k];
-		}
+		l_hexd[k] = a.g_hexd[k];
+		l_idz[k] = a.g_idz[k];
 		ldsg[k] = a.g_mg[k];
 	}
 	if (NE != 1 && a.lds_acc)
@@ -301,7 +291,7 @@ pc_trace_kernel(pc_kargs a)
 	__syncthreads();
 	pc_tables T;
 	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.ext = a.g_ext;
-	if (BATCH) { T.hexd = a.g_hexd; T.idz = a.g_idz; } else { T.hexd = l_hexd; T.idz = l_idz; }
+	T.hexd = l_hexd; T.idz = l_idz;
 	T.mg = ldsg;
 	const long long fs = a.img_fs, ss = a.img_ss, ws = a.img_ws;      /* strides of the image store: records or planes (pc_kargs) */
 	const pc_params &Pm = a.pm;
@@ -319,7 +309,6 @@ pc_trace_kernel(pc_kargs a)
 	ph.rc = 0;
 
 	int state = LS_NEED_SLOT;
-	int npend = 0;                /* NE == 0, a.lds_pend: reflections of this lane's photon waiting in l_pend */
 	long long slot = -1;          /* relative slot index in [0, n_slots) */
 	unsigned int attempt = 0;
 	double cosalpha0 = 0.;         /* start_electric_vector . start_direction: projection constants of src/polycap-source.c:789-796 */
@@ -336,157 +325,7 @@ pc_trace_kernel(pc_kargs a)
 	/* wave-uniform scheduler statistics (diagnostics: lane utilisation per phase type) */
 	unsigned long long st_march = 0, st_march_l = 0, st_event = 0, st_event_l = 0, st_new = 0, st_new_l = 0;
 
-	/* Many energies (a.lds_pend): a reflection only pushes its geometry (cos theta, (E.s)^2, |n x d|^2: the rest of
-	 * pc_refl_geom follows from them by the expressions that made it) and the photon flies on as if it had survived; its
-	 * weights are swept once per PC_KB reflections -- one load and one store per energy instead of PC_KB, every energy
-	 * still multiplied in the reference's order, so the weights are the same bits.  The sweep finds the first waiting
-	 * reflection that absorbs the photon (no weight >= 1e-4 left) or fails (return -1): the photon then ends there, as in
-	 * the reference, and what it did afterwards is dropped (a photon that ends with rc -1/0/1 is swept before it is
-	 * finalised, so nothing speculative is ever counted). */
-	double *const l_pend = BATCH ? (double *)(l_acc + 2*a.pm.n_energies) + 6*a.pm.n_energies : nullptr;
-	/* The sweep is FLAT over (photon, energy) pairs: the photons of the wave whose reflections are due form one list of
-	 * nP x n_energies items, lane l takes items l, l + 64, ...  (291 energies fill 4.55 passes of one photon -- 9 % idle lanes --
-	 * but 12 photons, the usual number after an EVENT phase, fill 54.6 of 55).  Per wave, in LDS behind the waiting reflections:
-	 * map[rank] = lane | n << 8 | wset << 16 of the rank-th photon, and its verdict: vcnt = reflections of the batch after which
-	 * some energy still holds >= 1e-4 (a weight never grows: the count of an energy is its number of leading "keep"s, the
-	 * photon's the maximum), vbad = first reflection whose rtot the reference rejects at some energy (255: none). */
-	unsigned int *const l_map = l_pend ? (unsigned int *)(l_pend + (size_t)blockDim.x*(3*PC_KB)) + (threadIdx.x >> 6)*(3*PC_WAVE) : nullptr;
-	auto flush_as = [&](unsigned long long mF, auto rough_tag) __attribute__((always_inline)) {
-		constexpr bool ROUGH = decltype(rough_tag)::value;
-		const double *ecs = (const double *)(l_acc + 2*a.pm.n_energies);      /* a.lds_pend implies a.lds_ec */
-		const long long wave_gtid0 = gtid - lane;
-		const int wave_t0 = (int)(threadIdx.x - lane);
-		unsigned int *map = l_map, *vcnt = l_map + PC_WAVE, *vbad = l_map + 2*PC_WAVE;
-		const int mine = (int)((mF >> lane) & 1ull);
-		const int rank = __popcll(mF & ((1ull << lane) - 1ull));
-		if (mine) {
-			map[rank] = (unsigned)lane | ((unsigned)npend << 8) | (ph.wset ? 0x10000u : 0u);
-			vcnt[rank] = 0u; vbad[rank] = 255u;
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		const int total = __popcll(mF)*ne;
-		int q = 0, e = lane;
-		while (e >= ne) { e -= ne; q++; }
-		/* PC_SWEEP_IL items per lane are in flight together: independent Fresnel chains for the fp64 pipe, and the next group's
-		 * weights are fetched while the current one is computed (the rows live in HBM) */
-		constexpr int IL = PC_SWEEP_IL;
-		unsigned info_n[IL]; double w_n[IL]; int q_n[IL], e_n[IL];
-#pragma unroll
-		for (int il = 0; il < IL; il++) {
-			q_n[il] = q; e_n[il] = e;
-			info_n[il] = 0u; w_n[il] = 1.0;
-			if (il*PC_WAVE + lane < total) {
-				info_n[il] = map[q];
-				if (info_n[il] >> 16) w_n[il] = a.wscratch[(wave_gtid0 + (info_n[il] & 255u))*(long long)ne + e];
-			}
-			e += PC_WAVE;
-			while (e >= ne) { e -= ne; q++; }
-		}
-		for (int base = 0; base < total; base += PC_WAVE*IL) {
-			int act[IL], qc[IL], ec_i[IL], n[IL], p[IL];
-			unsigned cnt[IL];
-			double w[IL];
-			const double *gq[IL];
-			double n_re[IL], n_im[IL], a_re[IL], a_im[IL], rgh[IL];
-			bool odd[IL];
-#pragma unroll
-			for (int il = 0; il < IL; il++) {
-				act[il] = base + il*PC_WAVE + lane < total;
-				const unsigned info = info_n[il];
-				w[il] = w_n[il]; qc[il] = q_n[il]; ec_i[il] = e_n[il];
-				p[il] = (int)(info & 255u);
-				n[il] = act[il] ? (int)((info >> 8) & 255u) : 0;
-				cnt[il] = 0u; odd[il] = false;
-				/* an idle lane computes on photon 0 / energy e of its position (valid addresses) and stores nothing */
-				gq[il] = l_pend + (size_t)(wave_t0 + p[il])*(3*PC_KB);
-				const int ee = act[il] ? ec_i[il] : 0;
-				n_re[il] = ecs[ee]; n_im[il] = ecs[ne + ee]; a_re[il] = ecs[2*ne + ee]; a_im[il] = ecs[3*ne + ee];
-				rgh[il] = ROUGH ? ecs[4*ne + ee] : 0.;
-			}
-#pragma unroll
-			for (int il = 0; il < IL; il++) {
-				q_n[il] = q; e_n[il] = e;
-				info_n[il] = 0u; w_n[il] = 1.0;
-				if (base + (IL + il)*PC_WAVE + lane < total) {
-					info_n[il] = map[q];
-					if (info_n[il] >> 16) w_n[il] = a.wscratch[(wave_gtid0 + (info_n[il] & 255u))*(long long)ne + e];
-				}
-				e += PC_WAVE;
-				while (e >= ne) { e -= ne; q++; }
-			}
-#pragma unroll
-			for (int r = 0; r < PC_KB; r++) {
-				bool any = false;
-#pragma unroll
-				for (int il = 0; il < IL; il++) any |= r < n[il];
-				if (__ballot(any) == 0ull) break;
-#pragma unroll
-				for (int il = 0; il < IL; il++) {
-					const bool ok = r < n[il];
-					if (IL == 1 && !ok) continue;        /* one item per lane: lanes without this reflection sit it out (with more items the loop is branch-free) */
-					const double ct = gq[il][3*r], es2 = gq[il][3*r + 1], sd2 = gq[il][3*r + 2];
-					double rt;
-					const double f = pc_fresnel_fast<ROUGH>(n_re[il], n_im[il], a_re[il], a_im[il], rgh[il], ct, fma(-ct, ct, 1.0), es2, sd2 - es2, sd2, rt);
-					odd[il] |= ok && ((unsigned long long)__double_as_longlong(rt) > 0x3FF0000000000000ull);   /* negative, above 1 or NaN: looked at below */
-					w[il] = w[il]*((IL == 1 || ok) ? f : 1.0);
-					cnt[il] += (ok && w[il] >= 1.e-4) ? 1u : 0u;
-				}
-			}
-			bool short_any = false;
-#pragma unroll
-			for (int il = 0; il < IL; il++) {
-				if (act[il]) a.wscratch[(wave_gtid0 + p[il])*(long long)ne + ec_i[il]] = w[il];
-				if (odd[il]) {
-					/* never with physical constants: find this energy's first rejected reflection (rtot does not depend on the weight) */
-					unsigned fb = 255u;
-					for (int r = n[il] - 1; r >= 0; r--) {
-						const double ct = gq[il][3*r], es2 = gq[il][3*r + 1], sd2 = gq[il][3*r + 2];
-						double rt;
-						(void)pc_fresnel_fast<false>(n_re[il], n_im[il], a_re[il], a_im[il], 0., ct, fma(-ct, ct, 1.0), es2, sd2 - es2, sd2, rt);
-						if (rt < 0. || rt > 1.) fb = (unsigned)r;
-					}
-					atomicMin(&vbad[qc[il]], fb);
-				}
-				short_any |= act[il] && cnt[il] < (unsigned)n[il];
-			}
-			/* verdict: nearly always every energy of the pass kept its weight above 1e-4 through the whole batch -- then one
-			 * lane per photon says so; else every lane reports its count */
-			if (__ballot(short_any) == 0ull) {
-#pragma unroll
-				for (int il = 0; il < IL; il++) {
-					const int q_left = __shfl_up(qc[il], 1, PC_WAVE);
-					if (act[il] && (lane == 0 || q_left != qc[il])) atomicMax(&vcnt[qc[il]], cnt[il]);
-				}
-			} else {
-#pragma unroll
-				for (int il = 0; il < IL; il++)
-					if (act[il]) atomicMax(&vcnt[qc[il]], cnt[il]);
-			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		if (mine) {
-			/* first waiting reflection that ends the photon: an error at any energy (rc -1), or no energy left above 1e-4 (rc 0) */
-			const unsigned c = vcnt[rank], b = vbad[rank];
-			const unsigned fail = (c < b) ? c : b;
-			if (fail < (unsigned)npend) { state = LS_DONE; ph.rc = (b <= c) ? -1 : 0; }
-			npend = 0;
-			ph.wset = 1;
-		}
-	};
-	auto flush = [&](unsigned long long mF) __attribute__((always_inline)) {
-		if (a.sweep_rough) flush_as(mF, std::true_type{});
-		else flush_as(mF, std::false_type{});
-	};
-
 	for (;;) {
-		if (BATCH) {
-			/* weights are swept when a photon's PC_KB places are full, and before a finished photon is finalised (the one place
-			 * the sweep is instantiated: every photon that is due goes into the same flat list) */
-			const unsigned long long mF = __ballot(npend == PC_KB || (state == LS_DONE && npend > 0));
-			if (mF) flush(mF);
-		}
 		const unsigned long long mM = __ballot(state == LS_MARCH);
 		const unsigned long long mE = __ballot(state == LS_EVENT);
 		const unsigned long long mN = __ballot(state == LS_DONE || state == LS_NEED_SLOT || state == LS_START);
@@ -532,11 +371,12 @@ pc_trace_kernel(pc_kargs a)
 				int pend = 0, res = 0;
 				h.nx = h.ny = h.nz = h.cosalfa = 0.; h.ix = 0;
 				g.alfa = g.st2 = g.es2 = g.ep2 = g.sd2 = 0.;
+				double g_c2 = 0., g_fs = 0., g_fp = 0.;      /* what FORM 3 takes from the geometry (pc_refl_geom3) */
 				if (state == LS_EVENT) {
 					int st = pc_event_pre(T, Pm, ph, h);
 					if (st == PC_ST_REFLECT) {
 						if (pc_reflect_geom(ph, h.nx, h.ny, h.nz, g) < 0) { pend = 2; res = -1; }
-						else pend = 1;
+						else { pend = 1; pc_refl_geom3(g, g_c2, g_fs, g_fp); }
 					} else {
 						state = st;
 					}
@@ -553,13 +393,7 @@ pc_trace_kernel(pc_kargs a)
 						const int G = (ne <= 16) ? 16 : 32, PP = PC_WAVE / G;
 						const int sub = lane / G, e = lane - sub*G;
 						const unsigned long long gm = (G == 32) ? 0xffffffffull : 0xffffull;
-						pc_energy_const ec;
-						ec.n_re = ec.n_im = ec.ninv2_re = ec.ninv2_im = ec.rough_c = ec.valid = 0.;
-						if (e < ne) {
-							ec.n_re = ecs[e]; ec.n_im = ecs[ne + e];
-							ec.ninv2_re = ecs[2*ne + e]; ec.ninv2_im = ecs[3*ne + e];
-							ec.rough_c = ecs[4*ne + e]; ec.valid = ecs[5*ne + e];
-						}
+						const pc_energy_const ec = pc_ec_from_soa(ecs, ne, (e < ne) ? e : 0);
 						while (mP) {
 							int srcv[4], myslot = -1;
 	#pragma unroll
@@ -583,12 +417,11 @@ pc_trace_kernel(pc_kargs a)
 	#pragma unroll
 							for (int j = 0; j < 4; j++) {
 								const int from = (srcv[j] < 0) ? 0 : srcv[j];
-								pc_refl_geom gp;
-								gp.alfa = __shfl(g.alfa, from, PC_WAVE); gp.st2 = __shfl(g.st2, from, PC_WAVE);
-								gp.es2 = __shfl(g.es2, from, PC_WAVE); gp.ep2 = __shfl(g.ep2, from, PC_WAVE); gp.sd2 = __shfl(g.sd2, from, PC_WAVE);
+								const double p_c = __shfl(g.alfa, from, PC_WAVE), p_c2 = __shfl(g_c2, from, PC_WAVE);
+								const double p_fs = __shfl(g_fs, from, PC_WAVE), p_fp = __shfl(g_fp, from, PC_WAVE);
 								int bad = 0, keep = 0;
 								if (srcv[j] >= 0 && e < ne) {
-									int r = pc_reflect_energy_sweep(ec, gp, wv[j], a.sweep_rough);
+									int r = pc_reflect_energy_sweep(ec, p_c, p_c2, p_fs, p_fp, wv[j]);
 									a.wscratch[(wave_gtid0 + srcv[j])*(long long)ne + e] = wv[j];
 									bad = (r < 0);
 									keep = (r > 0);
@@ -608,9 +441,8 @@ pc_trace_kernel(pc_kargs a)
 					while (mP) {
 						const int p = __ffsll((long long)mP) - 1;
 						mP &= mP - 1ull;
-						pc_refl_geom gp;
-						gp.alfa = __shfl(g.alfa, p, PC_WAVE); gp.st2 = __shfl(g.st2, p, PC_WAVE);
-						gp.es2 = __shfl(g.es2, p, PC_WAVE); gp.ep2 = __shfl(g.ep2, p, PC_WAVE); gp.sd2 = __shfl(g.sd2, p, PC_WAVE);
+						const double p_c = __shfl(g.alfa, p, PC_WAVE), p_c2 = __shfl(g_c2, p, PC_WAVE);
+						const double p_fs = __shfl(g_fs, p, PC_WAVE), p_fp = __shfl(g_fp, p, PC_WAVE);
 						const int wset_p = __shfl(ph.wset, p, PC_WAVE);
 						double *wp = a.wscratch + (wave_gtid0 + p)*(long long)ne;
 						int bad = 0, keep = 0;
@@ -626,11 +458,8 @@ pc_trace_kernel(pc_kargs a)
 							for (int k = 0; k < PC_KE; k++) {
 								const int e = e0 + k*PC_WAVE + lane;
 								if (e < ne) {
-									pc_energy_const ec;
-									ec.n_re = ecs[e]; ec.n_im = ecs[ne + e];
-									ec.ninv2_re = ecs[2*ne + e]; ec.ninv2_im = ecs[3*ne + e];
-									ec.rough_c = ecs[4*ne + e]; ec.valid = ecs[5*ne + e];
-									int r = pc_reflect_energy_sweep(ec, gp, wv[k], a.sweep_rough);
+									const pc_energy_const ec = pc_ec_from_soa(ecs, ne, e);
+									int r = pc_reflect_energy_sweep(ec, p_c, p_c2, p_fs, p_fp, wv[k]);
 									wp[e] = wv[k];
 									bad |= (r < 0);
 									keep |= (r > 0);
@@ -641,20 +470,10 @@ pc_trace_kernel(pc_kargs a)
 						if (lane == p) res = anybad ? -1 : (anykeep ? 1 : 0);
 					}
 				};
-				if (BATCH) {
-					/* the reflection waits (see flush above); the photon goes on as a survivor.  A geometry the reference rejects
-					 * (pend == 2) ends the photon with rc -1 unless a waiting reflection ends it first: both are settled
-					 * by the sweep that precedes the finalisation of every finished photon */
-					if (pend == 1) {
-						double *gq = l_pend + (size_t)threadIdx.x*(3*PC_KB) + 3*npend;
-						gq[0] = g.alfa; gq[1] = g.es2; gq[2] = g.sd2;
-						npend++;
-						res = 1;
-					}
-				} else if (NE == 0 && a.lds_ec) sweep((const double *)(l_acc + 2*a.pm.n_energies));
+				if (NE == 0 && a.lds_ec) sweep((const double *)(l_acc + 2*a.pm.n_energies));
 				else sweep(a.ec_soa);
 				if (pend) {
-					if (pend == 1) { if (!BATCH) ph.wset = 1; ph.ex = fabs(ph.ex); ph.ey = fabs(ph.ey); ph.ez = fabs(ph.ez); }
+					if (pend == 1) { ph.wset = 1; ph.ex = fabs(ph.ex); ph.ey = fabs(ph.ey); ph.ez = fabs(ph.ez); }
 					state = pc_event_post(Pm, ph, h, res);
 				}
 			}
@@ -688,10 +507,8 @@ pc_trace_kernel(pc_kargs a)
 					if (rc == 0) f_not_trans = 1;
 					else if (rc == 2) f_not_entered = 1;
 					else if (rc == 1) ok = pc_in_exit_window(Pm, ph);
-					if constexpr (!BATCH) {
-						/* what a leak run of the same slots is ordered by (pc_leak_auto_order) */
-						if (a.work_est) atomicAdd(&a.work_est[slot], (unsigned int)ph.irefl + 1u);
-					}
+					/* what a leak run of the same slots is ordered by (pc_leak_auto_order) */
+					if (a.work_est) atomicAdd(&a.work_est[slot], (unsigned int)ph.irefl + 1u);
 				}
 			}
 			/* compact store: the exit photons of this phase take the next positions of the planes, one coalesced run per plane */
@@ -901,7 +718,10 @@ pc_trace_kernel(pc_kargs a)
 
 #include "pc_pool_kernel.h"
 #include "pc_producer_kernel.h"
-#include "pc_wave_kernel.h"
+#ifdef PC_EXPERIMENTS
+#include "pc_wave_kernel.h"      /* the one-wave-per-photon experiment (profiles/r03/wave_per_photon_ab.txt): not part of the product build */
+#endif
+#include "pc_sweep_kernel.h"
 
 /* Image records (one contiguous record of 17 + n_energies doubles per slot) -> the planes of struct _polycap_images: 17
  * planes of n_total doubles each, then the weights as [slot][n_energies].  A workgroup stages PC_SOA_TILE records in LDS
@@ -1089,7 +909,15 @@ struct pc_hip_ctx {
 	int event_march = 0;
 	int pool_new_min = 48;
 	int lds_ec = 1;                /* many-energy runs: per-energy constants in LDS, one 1024-thread workgroup per CU */
-	int batch_reflections = 1;     /* more than 32 energies: sweep a photon's weights once per PC_KB reflections */
+	int batch_reflections = 1;     /* more than 32 energies, source runs: 1 = reflections are logged and a photon's weights swept once per log
+	                                * (pc_sweep_kernel.h), 0 = every reflection sweeps the weights at once */
+	int log_cap = 64;              /* option "log_cap": reflections per log of pc_trace_log_kernel */
+	int sweep_skip = 1;            /* option "sweep_skip": histogram-only log runs stop multiplying a weight below 2^-64 */
+	double *d_rlog = nullptr;
+	size_t rlog_elems = 0;
+	int sweep_cert = 0;            /* pc_sweep_certificate has run */
+	double sweep_ct_tame = 1.;
+	int sweep_n_proxy = 0, sweep_proxy_e[2] = {0, 0};
 	/* last run */
 	pc_totals *d_totals = nullptr;         /* pc_totals + 2*nE u64 */
 	size_t totals_bytes = 0;
@@ -1216,12 +1044,80 @@ static void pc_fill_common(pc_hip_ctx *ctx, pc_kargs &a)
 	a.sumw = (unsigned long long *)(ctx->d_totals + 1);
 }
 
-/* dynamic LDS of the any-n_energies kernel: exact sums, per-energy constants and -- batched kernel -- the waiting reflections
- * and the per-wave tables of the flat sweep */
-static size_t pc_ne0_dyn_lds(size_t ne, int lds_acc, int lds_ec, int lds_pend, int block)
+/* dynamic LDS of the any-n_energies kernel: exact sums and per-energy constants */
+static size_t pc_ne0_dyn_lds(size_t ne, int lds_acc, int lds_ec)
 {
-	return (lds_acc ? 2*ne*sizeof(unsigned long long) : 0) + (lds_ec ? 6*ne*sizeof(double) : 0)
-	     + (lds_pend ? (size_t)block*3*PC_KB*sizeof(double) + (size_t)(block/PC_WAVE)*3*PC_WAVE*sizeof(unsigned int) : 0);
+	return (lds_acc ? 2*ne*sizeof(unsigned long long) : 0) + (lds_ec ? 6*ne*sizeof(double) : 0);
+}
+
+
+/* What pc_trace_log_kernel needs to know about the run's energies (once per context):
+ *   ct_tame -- a cosine of the angle to the surface normal above which every energy's reflectivity stays at least 1e-11 below 1
+ *     (and, being a ratio of sums of squares weighted by fs, fp >= -1e-16, above 0): no factor of such a reflection can be
+ *     rejected by the reference's range test (src/polycap-capil.c:633-637) and every weight only falls.  Found by evaluating
+ *     1 - R_s = 4 c Re(g) / |c + g|^2 and 1 - R_p = 4 c Re(conj(g) n^2) / |g + n^2 c|^2, g = sqrt(n^2 - sin^2) from the device's own
+ *     constants (pc_fresnel3), in extended precision on 64 points per decade of c from 1 down to 1e-13, per energy: ct_tame =
+ *     4 x the largest grid point at which some energy comes closer than 1e-11 (the device's factors are good to ~2e-14).
+ *     Below the critical angle 1 - R ~ 4 c beta / (2 delta)^1.5, so for glass ct_tame ~ 1e-11.
+ *   proxies -- the energies that reflect best at 3 and at 30 mrad (roughness included): the last ones to fall below 1e-4. */
+static void pc_sweep_certificate(pc_hip_ctx *ctx)
+{
+	if (ctx->sweep_cert) return;
+	const std::vector<pc_energy_const> &ec = ctx->host.ec;
+	const int ne = (int)ec.size();
+	auto refl = [](const pc_energy_const &k, long double c, long double &one_minus_rs, long double &one_minus_rp) {
+		const long double zr = c*c - (long double)k.d2, zi = k.n2_im;
+		const long double mag = sqrtl(zr*zr + zi*zi);
+		long double gr = sqrtl(0.5L*(mag + fabsl(zr))), gi = (gr > 0.0L) ? 0.5L*fabsl(zi)/gr : 0.0L;
+		if (zr < 0.0L) { const long double x = gr; gr = gi; gi = x; }
+		if (zi < 0.0L) gi = -gi;
+		const long double ar = (long double)k.n2_re*c, ai = (long double)k.n2_im*c;
+		one_minus_rs = 4.0L*c*gr/((c + gr)*(c + gr) + gi*gi);
+		one_minus_rp = 4.0L*(gr*ar + gi*ai)/((gr + ar)*(gr + ar) + (gi + ai)*(gi + ai));
+	};
+	long double worst = 0.0L;               /* largest grid point at which some energy is not safely below 1 */
+	const long double step = powl(10.0L, -1.0L/64.0L);
+	for (int e = 0; e < ne; e++) {
+		long double c = 1.0L;
+		for (int k = 0; k <= 13*64; k++, c *= step) {
+			long double a, b;
+			refl(ec[e], c, a, b);
+			if (!(a >= 1.e-11L && b >= 1.e-11L) || !(a <= 1.0L && b <= 1.0L)) { if (c > worst) worst = c; break; }   /* scanning downwards: the first failure is the largest */
+		}
+	}
+	long double tame = 4.0L*worst;
+	if (tame < 4.e-13L) tame = 4.e-13L;     /* below the scanned range nothing is certified */
+	ctx->sweep_ct_tame = (tame > 2.0L) ? 2.0 : (double)tame;      /* 2: no reflection is tame (cos theta <= 1) */
+	int best[2] = {0, 0};
+	const long double at[2] = {3.e-3L, 3.e-2L};
+	for (int j = 0; j < 2; j++) {
+		long double top = -1.0L;
+		for (int e = 0; e < ne; e++) {
+			long double a, b;
+			refl(ec[e], at[j], a, b);
+			const long double x = (long double)ec[e].rough_c*at[j];
+			const long double r = (1.0L - 0.5L*(a + b))*expl(-x*x);
+			if (r > top) { top = r; best[j] = e; }
+		}
+	}
+	ctx->sweep_proxy_e[0] = best[0]; ctx->sweep_proxy_e[1] = best[1];
+	ctx->sweep_n_proxy = (best[0] == best[1]) ? 1 : 2;
+	ctx->sweep_cert = 1;
+}
+
+/* pc_trace_log_kernel applies to source runs with more than 32 valid energies on a profile of up to 1024 points whose sums and
+ * constants fit in LDS beside a stage of at least one log per wave; returns the stage size (doubles per wave), 0 if not */
+static size_t pc_log_stage_doubles(const pc_hip_ctx *ctx, int ne, int log_cap)
+{
+	const size_t fixed = 4*PCS_PITCH*sizeof(double) + PCS_PITCH*sizeof(pc_marg4) + pcs_dyn_lds((size_t)ne, PCS_BLOCK, 0);
+	if (fixed >= 163840) return 0;
+	size_t per_wave = ((163840 - fixed)/(PCS_BLOCK/PC_WAVE))/sizeof(double);
+	const size_t one = PCS_ENT*(size_t)log_cap;
+	if (per_wave < one) return 0;
+	size_t ps = per_wave/one;
+	if (ps > PCS_MAXPS) ps = PCS_MAXPS;
+	(void)ctx;
+	return ps*one;
 }
 
 template <int NE, int MODE>
@@ -1229,15 +1125,8 @@ static int pc_launch_one(pc_hip_ctx *ctx, const pc_kargs &a, int grid)
 {
 	/* table pitch: 1024 entries (48 KB of LDS) covers the reference's generated profiles (nmax = 999) and its example decks */
 	const int block = (int)(a.total_threads / grid);
-	const size_t dyn = (NE == 0) ? pc_ne0_dyn_lds((size_t)ctx->host.pm.n_energies, a.lds_acc, a.lds_ec, a.lds_pend, block)
+	const size_t dyn = (NE == 0) ? pc_ne0_dyn_lds((size_t)ctx->host.pm.n_energies, a.lds_acc, a.lds_ec)
 	                             : ((NE != 1 && a.lds_acc) ? 2*(size_t)ctx->host.pm.n_energies*sizeof(unsigned long long) : 0);
-	if constexpr (NE == 0 && MODE != PC_MODE_EXPLICIT) {
-		if (a.lds_pend) {
-			hipLaunchKernelGGL((pc_trace_kernel<0, MODE, 1024, true>), dim3(grid), dim3(block), dyn, ctx->stream, a);
-			PC_HIP_CHECK(hipGetLastError());
-			return PC_HIP_OK;
-		}
-	}
 	if (ctx->host.pm.nmax + 1 <= 1024)
 		hipLaunchKernelGGL((pc_trace_kernel<NE, MODE, 1024>), dim3(grid), dim3(block), dyn, ctx->stream, a);
 	else if (NE <= 1)   /* long profiles: only the NE = 1 and the any-n_energies kernels are built for the 2048 pitch */
@@ -1274,17 +1163,17 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 	/* many energies on a profile of up to 1024 points: one workgroup of 1024 threads per CU (the same 16 waves as two of
 	 * 512) leaves room in LDS for the per-energy constants next to the tables and the sums */
 	a.lds_ec = (kne == 0 && a.lds_acc && ctx->lds_ec && ctx->host.pm.nmax + 1 <= 1024 && 64*(size_t)ne <= 28672) ? 1 : 0;
-	/* more than 32 energies: PC_KB reflections per sweep of a photon's weights (their geometry waits in LDS: 96 B per lane) */
 	bool all_valid = true;
 	a.sweep_rough = 0;
 	for (const pc_energy_const &c : ctx->host.ec) {
 		if (c.valid == 0.) all_valid = false;
 		if (c.rough_c != 0.) a.sweep_rough = 1;
 	}
-	a.lds_pend = (a.lds_ec && ne > 32 && ctx->batch_reflections && all_valid && MODE != PC_MODE_EXPLICIT
-	              && 4*1024*sizeof(double) + 1024*sizeof(pc_marg4) + pc_ne0_dyn_lds((size_t)ne, 1, 1, 1, PC_BLOCK_BATCH) <= 163840) ? 1 : 0;   /* source runs only: an explicit
-	                                       * photon reports its state at the absorbing reflection, which the speculation overwrites */
+	/* source runs with more than 32 (valid) energies log their reflections (pc_trace_log_kernel); an explicit photon reports its
+	 * state at the absorbing reflection, which the logging kernel's speculation overwrites */
+	const bool want_log = a.lds_ec && ne > 32 && ctx->batch_reflections && all_valid && MODE != PC_MODE_EXPLICIT;
 	if constexpr (MODE != PC_MODE_EXPLICIT) {
+#ifdef PC_EXPERIMENTS
 		if (ctx->wave_per_photon && ne == 1 && !a.keep_images && ctx->host.pm.nmax + 1 <= 1024) {
 			/* the experiment of pc_wave_kernel.h: one wave per photon, 16 waves per CU */
 			long long want = (n_items + 3) / 4;
@@ -1298,6 +1187,7 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 			if (ctx->rec_ev1) PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
 			return PC_HIP_OK;
 		}
+#endif
 		const pc_params &pm = ctx->host.pm;
 		const bool want_producer = ctx->producer == 1 || (ctx->producer < 0 && !ctx->in_probe && ctx->refl_per_launch >= PC3_MIN_REFL);
 		if (want_producer && pm.n_energies == 1 && !ctx->literal && pm.nmax + 1 <= PC3_PITCH && a.max_attempts <= (1u << 24)
@@ -1338,8 +1228,46 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		if (ctx->rec_ev1) PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
 		return PC_HIP_OK;
 	}
+	if constexpr (MODE != PC_MODE_EXPLICIT) {
+		const size_t stage = want_log ? pc_log_stage_doubles(ctx, ne, ctx->log_cap) : 0;
+		if (stage) {
+			/* reflections are logged, a photon's weights swept once per log (pc_sweep_kernel.h): one workgroup of 12 waves per CU */
+			pc_sweep_certificate(ctx);
+			long long want = (n_items + PCS_BLOCK - 1) / PCS_BLOCK;
+			int grid = (int)(want < pc_cus(ctx) ? want : pc_cus(ctx));
+			if (grid < 1) grid = 1;
+			a.total_threads = (long long)grid * PCS_BLOCK;
+			const size_t need_w = (size_t)ne * (size_t)a.total_threads, need_l = 3*(size_t)ctx->log_cap * (size_t)a.total_threads;
+			if (need_w > ctx->wscratch_elems) {
+				if (ctx->d_wscratch) PC_HIP_CHECK(hipFree(ctx->d_wscratch));
+				ctx->d_wscratch = nullptr; ctx->wscratch_elems = 0;
+				if (hipMalloc(&ctx->d_wscratch, need_w*sizeof(double)) != hipSuccess) return pc_fail(PC_HIP_ERR_MEMORY, "could not allocate the per-lane weight scratch");
+				ctx->wscratch_elems = need_w;
+			}
+			if (need_l > ctx->rlog_elems) {
+				if (ctx->d_rlog) PC_HIP_CHECK(hipFree(ctx->d_rlog));
+				ctx->d_rlog = nullptr; ctx->rlog_elems = 0;
+				if (hipMalloc(&ctx->d_rlog, need_l*sizeof(double)) != hipSuccess) return pc_fail(PC_HIP_ERR_MEMORY, "could not allocate the reflection logs");
+				ctx->rlog_elems = need_l;
+			}
+			a.wscratch = ctx->d_wscratch;
+			a.rlog = ctx->d_rlog;
+			a.log_cap = ctx->log_cap;
+			a.stage_ps = (int)(stage/(PCS_ENT*(size_t)ctx->log_cap));
+			a.flush_min = std::max(1, std::min(a.stage_ps, (256 + ne - 1)/ne));
+			a.n_proxy = ctx->sweep_n_proxy; a.proxy_e[0] = ctx->sweep_proxy_e[0]; a.proxy_e[1] = ctx->sweep_proxy_e[1];
+			a.ct_tame = ctx->sweep_ct_tame;
+			a.sweep_skip = (ctx->sweep_skip && !a.keep_images) ? 1 : 0;
+			if (ctx->rec_ev0) PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+			hipLaunchKernelGGL((pc_trace_log_kernel<MODE>), dim3(grid), dim3(PCS_BLOCK), pcs_dyn_lds((size_t)ne, PCS_BLOCK, stage), ctx->stream, a);
+			ctx->last_kernel = 4;
+			PC_HIP_CHECK(hipGetLastError());
+			if (ctx->rec_ev1) PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+			return PC_HIP_OK;
+		}
+	}
 	long long max_blocks = (long long)pc_cus(ctx) * ((kne == 0) ? 1 : ctx->blocks_per_cu);
-	const int block = (kne == 0 && a.lds_pend) ? PC_BLOCK_BATCH : ctx->block_size;      /* the batched many-energy kernel: 12 waves per CU */
+	const int block = ctx->block_size;
 	long long want_blocks = (n_items + block - 1) / block;
 	int grid = (int)(want_blocks < max_blocks ? want_blocks : max_blocks);
 	if (grid < 1) grid = 1;
@@ -1406,6 +1334,7 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->d_work) (void)hipFree(ctx->d_work);
 	if (ctx->ev_sync) (void)hipEventDestroy(ctx->ev_sync);
 	if (ctx->d_wscratch) (void)hipFree(ctx->d_wscratch);
+	if (ctx->d_rlog) (void)hipFree(ctx->d_rlog);
 	if (ctx->d_cursor) (void)hipFree(ctx->d_cursor);
 	if (ctx->d_blk_done) (void)hipFree(ctx->d_blk_done);
 	if (ctx->h_blk_flag) (void)hipHostFree(ctx->h_blk_flag);
@@ -1470,11 +1399,12 @@ int pc_hip_ctx_create(const pc_hip_problem *problem, int device, pc_hip_ctx **ou
 	}
 	{
 		const size_t ne = ctx->host.ec.size();
-		std::vector<double> soa(6*ne);
+		/* field-major constants of the weight sweeps (FORM 3): d2, Re n^2, Im n^2, max((Im n^2)^2, 2^-200), rough_c, valid, rough_c^2 */
+		std::vector<double> soa(7*ne);
 		for (size_t e = 0; e < ne; e++) {
 			const pc_energy_const &c = ctx->host.ec[e];
-			soa[e] = c.n_re; soa[ne + e] = c.n_im; soa[2*ne + e] = c.ninv2_re; soa[3*ne + e] = c.ninv2_im;
-			soa[4*ne + e] = c.rough_c; soa[5*ne + e] = c.valid;
+			soa[e] = c.d2; soa[ne + e] = c.n2_re; soa[2*ne + e] = c.n2_im; soa[3*ne + e] = c.zi2;
+			soa[4*ne + e] = c.rough_c; soa[5*ne + e] = c.valid; soa[6*ne + e] = c.rough_k2;
 		}
 		PC_CTX_CHECK(hipMalloc(&ctx->d_ec_soa, soa.size()*sizeof(double)));
 		PC_CTX_CHECK(hipMemcpy(ctx->d_ec_soa, soa.data(), soa.size()*sizeof(double), hipMemcpyHostToDevice));
@@ -1501,6 +1431,8 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "blocks_per_cu") { if (value < 1 || value > 8) return pc_fail(PC_HIP_ERR_INVALID, "blocks_per_cu must be in [1,8]"); ctx->blocks_per_cu = (int)value; }
 	else if (n == "lds_ec") ctx->lds_ec = value ? 1 : 0;
 	else if (n == "batch_reflections") ctx->batch_reflections = value ? 1 : 0;
+	else if (n == "log_cap") { if (value < 1 || value > 255) return pc_fail(PC_HIP_ERR_INVALID, "log_cap must be in [1,255]"); ctx->log_cap = (int)value; }
+	else if (n == "sweep_skip") ctx->sweep_skip = value ? 1 : 0;
 	else if (n == "plane_images") ctx->plane_images = value ? 1 : 0;
 	else if (n == "compact_images") ctx->compact_images = value ? 1 : 0;
 	else if (n == "slot_ids") ctx->slot_ids = value ? 1 : 0;
@@ -1509,7 +1441,13 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "run_parts") { if (value < 1 || value > PC_MAX_PARTS) return pc_fail(PC_HIP_ERR_INVALID, "run_parts must be in [1,16]"); ctx->run_parts = (int)value; }
 	else if (n == "fetch_threads") { if (value < 0 || value > 256) return pc_fail(PC_HIP_ERR_INVALID, "fetch_threads must be in [0,256]"); ctx->fetch_threads = (int)value; }
 	else if (n == "pool") ctx->pool = value ? 1 : 0;
-	else if (n == "wave_per_photon") ctx->wave_per_photon = value ? 1 : 0;
+	else if (n == "wave_per_photon") {
+#ifdef PC_EXPERIMENTS
+		ctx->wave_per_photon = value ? 1 : 0;
+#else
+		if (value) return pc_fail(PC_HIP_ERR_INVALID, "wave_per_photon: the experiment kernel is compiled only with -DPC_EXPERIMENTS (scripts/analysis/wave_per_photon_ab.py)");
+#endif
+	}
 	else if (n == "march_stats") ctx->march_stats = value ? 1 : 0;
 	else if (n == "cu_share") { if (value < 1 || value > 64) return pc_fail(PC_HIP_ERR_INVALID, "cu_share must be in [1,64]"); ctx->cu_share = (int)value; }
 	else if (n == "producer") { if (value < -1 || value > 1) return pc_fail(PC_HIP_ERR_INVALID, "producer must be -1 (automatic), 0 or 1"); ctx->producer = (int)value; }
@@ -2022,6 +1960,21 @@ int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6])
 	pc_totals t;
 	PC_HIP_CHECK(hipMemcpy(&t, ctx->d_totals, sizeof(t), hipMemcpyDeviceToHost));
 	for (int k = 0; k < 6; k++) stats[k] = (int64_t)t.phase[k];
+	return PC_HIP_OK;
+}
+
+int pc_hip_sweep_stats(pc_hip_ctx *ctx, int64_t stats[2], double *ct_tame, int proxies[2])
+{
+	if (!ctx || !stats) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_sweep_stats: NULL argument");
+	int st = pc_hip_transmission_wait(ctx, nullptr);
+	if (st) return st;
+	pc_totals t;
+	PC_HIP_CHECK(hipMemcpy(&t, ctx->d_totals, sizeof(t), hipMemcpyDeviceToHost));
+	const bool log_run = ctx->last_kernel == 4;
+	stats[0] = log_run ? (int64_t)t.phase[6] : 0;
+	stats[1] = log_run ? (int64_t)t.phase[7] : 0;
+	if (ct_tame) *ct_tame = ctx->sweep_cert ? ctx->sweep_ct_tame : -1.;
+	if (proxies) { proxies[0] = ctx->sweep_cert ? ctx->sweep_proxy_e[0] : -1; proxies[1] = (ctx->sweep_cert && ctx->sweep_n_proxy > 1) ? ctx->sweep_proxy_e[1] : -1; }
 	return PC_HIP_OK;
 }
 

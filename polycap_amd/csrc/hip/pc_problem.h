@@ -166,6 +166,12 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 		c.n_re = nre; c.n_im = nim;
 		c.ninv2_re = ire*ire - iim*iim; c.ninv2_im = 2.*(ire*iim);
 		c.rough_c = (1.01358e0*e)*p->sig_rough;
+		/* FORM 3 (pc_fresnel3): n^2 and d2 = 1 - Re n^2 = alfa (2 - alfa) + beta^2 */
+		c.d2 = alfa*(2.0 - alfa) + beta*beta;
+		c.n2_re = 1.0 - c.d2;
+		c.n2_im = 2.*(nre*nim);
+		c.zi2 = std::fmax(c.n2_im*c.n2_im, 6.223015277861142e-61 /* 2^-200 */);
+		c.rough_k2 = c.rough_c*c.rough_c;
 		/* argument checks of polycap_refl_polar, src/polycap-capil.c:463-478 */
 		c.valid = (e >= 1. && e <= 100. && p->density > 0. && scatf >= 0. && amu >= 0.) ? 1. : 0.;
 	}

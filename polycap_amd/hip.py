@@ -149,7 +149,8 @@ class TraceContext:
                     i_exit=int(cnt[0]), not_entered=int(cnt[1]), not_transmitted=int(cnt[2]), sum_irefl=int(cnt[3]),
                     failed_slots=int(cnt[4]), launches=int(cnt[5]), i_start=int(cnt[0] + cnt[1] + cnt[2]))
 
-    KERNELS = {0: "pc_trace_kernel", 1: "pc_trace_pool_kernel", 2: "pc_trace_producer_kernel", 3: "pc_trace_wave_kernel"}
+    KERNELS = {0: "pc_trace_kernel", 1: "pc_trace_pool_kernel", 2: "pc_trace_producer_kernel", 3: "pc_trace_wave_kernel",
+               4: "pc_trace_log_kernel"}
 
     def last_kernel(self):
         """Name of the kernel that traced the last source run (None before the first)."""
@@ -164,6 +165,17 @@ class TraceContext:
         names = ("march", "event", "new")
         return {n: dict(phases=int(st[2 * i]), lanes=int(st[2 * i + 1]),
                         avg_lanes=float(st[2 * i + 1]) / max(1, int(st[2 * i]))) for i, n in enumerate(names)}
+
+    def sweep_stats(self):
+        """Weight sweeps of the last run of the logging many-energy kernel: wave-level passes and (pass, reflection) iterations,
+        the host's tameness threshold and the proxy energies."""
+        st = np.zeros(2, dtype=np.int64)
+        ct = C.c_double(0.)
+        pr = (C.c_int * 2)(-1, -1)
+        rc = self._L.pc_hip_sweep_stats(self._h, st.ctypes.data_as(c_int64_p), C.byref(ct), pr)
+        if rc != _cabi.PC_HIP_OK:
+            raise HipError("pc_hip_sweep_stats", rc)
+        return dict(passes=int(st[0]), iterations=int(st[1]), ct_tame=float(ct.value), proxies=[int(pr[0]), int(pr[1])])
 
     def images(self, first=0, count=None):
         """Image data of slots [first, first+count) of the last run: images [count, 17] (the planes of pc_hip_images in

@@ -1,5 +1,6 @@
 """A/B of the photon-to-hardware mapping: one lane per photon with wave-wide phases (the product's
 kernels) against one wave per photon (pc_wave_kernel.h, the north_star's wording), xos1 at 10 keV, histogram only.
+    POLYCAP_EXPERIMENTS=1 python -m polycap_amd._build --force     # the experiment kernel is not part of the product build
     python scripts/analysis/wave_per_photon_ab.py [slots]      -> table on stdout (profiles/r03/wave_per_photon_ab.txt)"""
 import os
 import sys

@@ -26,6 +26,22 @@ def test_all_declared_symbols_are_exported():
         assert must in declared
 
 
+def test_nothing_but_the_c_abi_is_exported():
+    """The library is linked with a version script (polycap_amd/csrc/libpolycap.map; reference meson.build:85-100: default-hidden
+    visibility, POLYCAP_EXTERN only): no kernel host stub (_Z...), no weak libstdc++ instantiation, no HIP registration symbol in
+    the dynamic symbol table -- a C program that links another C++ library next to this one cannot get them interposed."""
+    import subprocess
+    import polycap_amd
+    polycap_amd.lib()
+    so = os.path.join(ROOT, "polycap_amd", "lib", "libpolycap.so")
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert len(names) > 90
+    allowed = re.compile(r"^(polycap_\w+|pc_hip_\w+|pc_transmission_efficiencies_\w+|pc_optconst_\w+|pc_source_problem|pc_hdf5_provider|pc_host_pool_clear)$")
+    extra = [n for n in names if not allowed.match(n)]
+    assert not extra, extra
+
+
 def test_forwarding_headers_compile(tmp_path):
     import subprocess
     src = tmp_path / "t.c"

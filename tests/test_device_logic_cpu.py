@@ -4,7 +4,7 @@ known answers.  The emulation is test tooling only; the product has no CPU trace
 import numpy as np
 import pytest
 
-from tests.common import make_pair, rel, PIN_AMU, PIN_SCATF
+from tests.common import synthetic_constants, PIN_E, make_pair, rel, PIN_AMU, PIN_SCATF
 
 
 @pytest.fixture(scope="module")
@@ -62,6 +62,32 @@ def test_single_reflection_reflectivity(emul, oracle, known):
         assert o["rc"] == rc and o["i_refl"] == rc and abs(o["weights"][0] - expect) < 1e-5
         assert r["rc"][0] == rc and r["i_refl"][0] == rc and abs(r["weights"][0, 0] - expect) < 1e-5
         assert rel(r["weights"][0], o["weights"]).max() < 1e-9
+
+
+def test_form3_reflectivity_of_many_energy_runs(emul, oracle):
+    """Runs whose weights live in memory (more than 8 energies) evaluate the Fresnel factor in FORM 3 (pc_fresnel3: g = sqrt(n^2 -
+    sin^2) formed directly, one reciprocal).  One reflection (a few at the steep angles) in a wide straight capillary at angles below, at and above the
+    critical angles of a 12-energy grid that contains the reference's pinned 10 keV point: the reference's published weights
+    (tests/capil.c:302-334) at that energy and the oracle's at all of them, with and without roughness."""
+    from polycap_amd import Problem
+    E = np.concatenate(([PIN_E], np.linspace(1.0, 30.0, 11)))
+    A, S = synthetic_constants(E)
+    A[0], S[0] = PIN_AMU, PIN_SCATF
+    z = np.linspace(0, 0.6, 201)
+    for sig in (0.0, 5.0):
+        prob = Problem(z, np.full(201, 1e-3), np.full(201, 0.05), sig, 7, 2.23, E, A, S)
+        opt = oracle.Optic(z, np.full(201, 1e-3), np.full(201, 0.05), sig, 7, 2.23)
+        for alfa, expect in ((2e-3, 0.984522), (3.1e-3, 0.496310), (2e-2, 0.000035), (1.7e-3, None), (4.5e-3, None), (0.3, None)):
+            d = (np.sin(alfa), 0.0, np.cos(alfa))
+            for ev in ((0, 1, 0), (0.6, 0.8, 0)):
+                o = oracle.launch_one(opt, E, A, S, (0, 0, 0.0), d, ev)
+                r = emul.launch_batch(prob, [[0, 0, 0.0]], [d], [ev])
+                assert r["rc"][0] == o["rc"] and r["i_refl"][0] == o["i_refl"]
+                # both sides carry ~1e-16 of absolute rounding in cos^2 - 2 delta (the reference's 1 - sin^2/n^2 cancels): relative
+                # 1e-10 ... 1e-9 of the reflectivity where it is steep
+                assert rel(r["weights"][0], o["weights"]).max() < 2e-9, (sig, alfa, rel(r["weights"][0], o["weights"]).max())
+                if expect is not None and sig == 0.0 and ev == (0, 1, 0) and o["i_refl"] == 1:
+                    assert abs(r["weights"][0, 0] - expect) < 1e-5
 
 
 def test_sampler_matches_oracle(emul, oracle):

@@ -407,9 +407,10 @@ def test_command_line_program(pa, tmp_path):
 
 def _same_photons_weights_to_rounding(g, e, rtol=1e-11):
     """Kernels whose weights live in memory (more than 8 energies, or several on a long profile) evaluate the Fresnel factor
-    with the hardware reciprocal square root / reciprocal + one Newton step (pc_device.h FORM 2, 4e-15 per factor); the host
-    compile uses IEEE sqrt and division in FORM 1.  The trajectory does not depend on the weights (only the "no weight above
-    1e-4 left" decision does): everything but the weights is identical bit for bit, the weights to accumulated rounding."""
+    in FORM 3 of pc_device.h with the hardware reciprocal square root / reciprocal + one Newton step (4e-15 per factor); the
+    host compile evaluates the same expressions with IEEE sqrt and division.  The trajectory does not depend on the weights
+    (only the "no weight above 1e-4 left" decision does): everything but the weights is identical bit for bit, the weights to
+    accumulated rounding."""
     for k in g:
         if k == "weights":
             assert np.all(np.abs(g[k] - e[k]) <= rtol * np.abs(e[k])), (k, np.max(np.abs(g[k] / e[k] - 1.0)))
@@ -448,7 +449,7 @@ def test_long_profile_uses_the_wide_lds_tables(pa, oracle):
 @pytest.mark.parametrize("n_energies", [12, 24, 40, 291])
 def test_many_energies_match_the_host_compile(pa, oracle, n_energies):
     """The any-n_energies kernel (weights in memory, cooperative sweeps: 4 photons per pass up to 16 energies, 2 up to 32,
-    one beyond; FORM 2 of the Fresnel factor) against the host compile of the device code -- every photon the same, bit for
+    one beyond; FORM 3 of the Fresnel factor) against the host compile of the device code -- every photon the same, bit for
     bit, except the weights, which agree to rounding -- and the driver against the oracle."""
     from tests.emul import pyemul
     energies = np.linspace(3.0, 30.0, n_energies)
@@ -508,23 +509,63 @@ def test_pool_and_producer_kernels_are_bit_identical(pa, oracle):
                 assert a["failed_slots"] > 0 and not done.all()
 
 
-def test_batched_reflections_equal_the_immediate_sweep(pa):
-    """Beyond 32 energies a source run pushes its reflections into LDS and sweeps a photon's weights once per four of them,
-    flying on as a survivor meanwhile (option batch_reflections, default on): counters, exact sums, every exit weight and
-    every image plane equal those of the immediate sweep, on the C3 and the C5 deck."""
+def test_logged_reflections_equal_the_immediate_sweep(pa):
+    """Beyond 32 energies a source run logs its reflections (24 B each) and sweeps a photon's weights once per log, the photon
+    flying on meanwhile (pc_trace_log_kernel, option batch_reflections, default on).  On the C3 deck counters, exact sums, every
+    exit weight and every image plane equal those of the immediate sweep bit for bit, with images kept and -- where weights below
+    2^-64 are no longer multiplied -- in histogram-only runs, for several log capacities.  On the C5 deck with roughness the
+    logging kernel applies a log's roughness factors as one exponential: photons and planes identical, weights to 1e-13."""
     import os
     from tests.conftest import EXAMPLE
     for deck, sig, n in (("xos1", None, 40000), ("ellip_l9", 5.0, 30000)):
         prob = pa.problem_from_inp(os.path.join(EXAMPLE, deck + ".inp"), sig_rough=sig)
         assert prob.n_energies == 291
-        out = []
         with pa.TraceContext(prob) as ctx:
-            for b in (0, 1):
-                ctx.set_option("batch_reflections", b)
-                out.append(ctx.transmission(77, 0, n, keep_images=True))
-        a, b = out
-        assert np.array_equal(a["counters"][:4], b["counters"][:4]) and np.array_equal(a["sumw_fixed"], b["sumw_fixed"]), deck
-        assert np.array_equal(a["exit_weights"], b["exit_weights"]) and np.array_equal(a["images"], b["images"], equal_nan=True), deck
+            ctx.set_option("batch_reflections", 0)
+            a = ctx.transmission(77, 0, n, keep_images=True)
+            assert ctx.last_kernel() == "pc_trace_kernel"
+            ctx.set_option("batch_reflections", 1)
+            for cap, keep in ((64, True), (64, False), (5, True), (200, False)):
+                ctx.set_option("log_cap", cap)
+                b = ctx.transmission(77, 0, n, keep_images=keep)
+                assert ctx.last_kernel() == "pc_trace_log_kernel"
+                st = ctx.sweep_stats()
+                assert st["passes"] > 0 and st["iterations"] > 0 and 0. < st["ct_tame"] < 1e-9
+                assert np.array_equal(a["counters"][:6], b["counters"][:6]), (deck, cap, keep)
+                if sig is None:
+                    assert np.array_equal(a["sumw_fixed"], b["sumw_fixed"]), (deck, cap, keep)
+                else:
+                    assert np.abs(b["sum_weights"] / a["sum_weights"] - 1.0).max() < 1e-14, (deck, cap, keep)
+                if keep:
+                    assert np.array_equal(a["images"], b["images"], equal_nan=True), (deck, cap)
+                    if sig is None:
+                        assert np.array_equal(a["exit_weights"], b["exit_weights"]), (deck, cap)
+                    else:
+                        assert np.nanmax(np.abs(b["exit_weights"] - a["exit_weights"]) / a["exit_weights"]) < 1e-13, (deck, cap)
+
+
+def test_logged_reflections_with_photons_that_die(pa, oracle):
+    """The logging kernel on grids whose photons are absorbed (10-30 keV: every energy falls below 1e-4 within a few steep
+    reflections): the lane's proxy energy triggers the sweep that ends the photon where the immediate sweep ends it -- counters
+    (not_transmitted included), sums and planes identical; and a run against the oracle."""
+    energies = np.linspace(10.0, 30.0, 40)
+    optic, src, prob, (E, A, S) = make_pair(oracle, "xos1", energies=energies)
+    with pa.TraceContext(prob) as ctx:
+        ctx.set_option("batch_reflections", 0)
+        a = ctx.transmission(5, 0, 60000, keep_images=True)
+        ctx.set_option("batch_reflections", 1)
+        b = ctx.transmission(5, 0, 60000, keep_images=True)
+        assert ctx.last_kernel() == "pc_trace_log_kernel"
+        c = ctx.transmission(5, 0, 60000)
+    assert a["not_transmitted"] > 1000
+    for r in (b, c):
+        assert np.array_equal(a["counters"][:6], r["counters"][:6]) and np.array_equal(a["sumw_fixed"], r["sumw_fixed"])
+    assert np.array_equal(a["exit_weights"], b["exit_weights"]) and np.array_equal(a["images"], b["images"], equal_nan=True)
+    o = oracle.transmission(optic, src, E, A, S, 5, 0, 20000)
+    with pa.TraceContext(prob) as ctx:
+        t = ctx.transmission(5, 0, 20000)
+    assert np.all(np.abs(t["efficiencies"] - o["efficiencies"]) <= 1.5 / np.sqrt(o["i_start"]) * o["efficiencies"] + 1e-12)
+    assert abs(t["not_transmitted"] - o["not_transmitted"]) <= 4 * np.sqrt(o["not_transmitted"])
 
 
 def test_kernel_choice_by_photon_lifetime(pa, oracle, monkeypatch):
