@@ -21,7 +21,8 @@ Weak scaling: every rank traces --photons slots.
 Extra legs, rank 0 at N = 1 only, after the timed region (each bounded to seconds):
   wall_incl_copyback  the same workload through the public C API with all 18 image planes copied back into host arrays
                       (SURVEY 8d's wall = kernel + reduce + result copy-back; never `value`)
-  sweep_291           BASELINE C3's kernel: xos1 on the deck's 291-energy grid, histogram only
+  sweep_291           BASELINE C3's kernel: xos1 on the deck's 291-energy grid, histogram only, launches of 1e6 and 4e6 slots
+  sweep_300           the same on BASELINE's literal "300-bin" grid, np.linspace(1, 30, 300)
   ellip_l9_rough      BASELINE C5's deck: ellip_l9.inp with sig_rough = 5 Angstrom, 1 and 291 energies
   leak_262144         leak_calc=true: the reference's test optic, 10 keV, 262144 exit photons
   parity_fixture      the metric's parity half at the north-star N: the 128 committed oracle runs (tests/golden/
@@ -42,7 +43,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0   # CUs x SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz
 # rocprofv3 --pmc passes of this same command, condensed by scripts/summarize_profile.py (profiles/README)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "headline_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04", "headline_pmc_summary.json")
 BYTES_PER_EXIT_PHOTON = 17 * 8   # 17 image planes of 8 B; + 8 B per energy for exit_coord_weights
 
 
@@ -158,10 +159,19 @@ def main():
         last = (counters, sums)
     barrier()
     wall = time.perf_counter() - t0
+    rccl = None
     if dist is not None:
         tt = torch.tensor([wall], dtype=torch.float64, device=red_dev if red_dev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
+        # one extra gather, outside the timed region: every rank's mean kernel time, so that the scaling record shows that the
+        # collective saw all the ranks and where the tail of a step is
+        mine = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=red_dev if red_dev is not None else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(x.item()) for x in every]
+        rccl = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                "per_rank_kernel_ms": [min(per_rank), max(per_rank)], "ranks_seen": len(per_rank)}
 
     if rank == 0:
         counters, sums = last
@@ -207,6 +217,7 @@ def main():
                        "exit_photons_per_gpu": n_local, "n_energies": ne, "images": keep_images,
                        "parallelism": "slots sharded over %d GPU(s), one RCCL all-reduce of the histogram per step" % world},
             "exit_photons_per_s": exited / wall,
+            "rccl": rccl,
             "efficiency_10keV": float(eff[0]),
             "avg_reflections": float(counters[3]) / max(1, int(counters[0])),
             "started_per_exit": started / max(1, exited),
@@ -225,10 +236,12 @@ def main():
         if world == 1 and not args.no_extras:
             if keep_images:
                 out["wall_incl_copyback"] = wall_incl_copyback(deck, n_local, started / float(args.steps * n_local))
-            out["sweep_291"] = side_workload("xos1", None, None, 1_000_000, dev_index, "profiles/r03/ne291_pmc_summary.json")
+            out["sweep_291"] = side_workload("xos1", None, None, 1_000_000, dev_index, "profiles/r04/ne291_pmc_summary.json")
+            out["sweep_291"]["launch_of_4e6_slots"] = side_workload("xos1", None, None, 4_000_000, dev_index)
+            out["sweep_300"] = side_workload("xos1", np.linspace(1.0, 30.0, 300), None, 1_000_000, dev_index)
             out["ellip_l9_rough"] = {"n_energies_1": side_workload("ellip_l9", [10.0], 5.0, 4_000_000, dev_index),
                                      "n_energies_291": side_workload("ellip_l9", None, 5.0, 500_000, dev_index,
-                                                                     "profiles/r03/ellip291_pmc_summary.json")}
+                                                                     "profiles/r04/ellip291_pmc_summary.json")}
             out["leak_262144"] = leak_workload(262_144, dev_index)
         if world == 1 and not args.no_extras:
             out["parity_fixture"] = parity_fixture(prob, dev_index)
@@ -266,10 +279,31 @@ def valu_issue(pmc, kernel_ms):
             "source": os.path.relpath(PMC_SUMMARY, ROOT) + " (rocprofv3 --pmc) / HIP-event kernel time of this run"}
 
 
+def pmc_block(pmc_file, kernel, kernel_ms):
+    """VALU issue rate, lane utilisation, wait share and HBM traffic of a leg from the committed rocprofv3 --pmc summary of exactly
+    its workload (scripts/profile_r04.sh + scripts/summarize_profile.py --kernel ...) over the kernel time measured here.  The
+    summary must name the kernel that ran here (tests/test_bench_contract.py checks the committed ones): else no block."""
+    try:
+        with open(os.path.join(ROOT, pmc_file)) as f:
+            pmc = json.load(f)
+    except Exception:
+        return {"missing": pmc_file}
+    named = pmc.get("meta", {}).get("kernel", "")
+    if not kernel or (kernel + "<") not in named:
+        return {"mismatch": "summary %s is of %r, this leg ran %r" % (pmc_file, named, kernel)}
+    rate = pmc["SQ_INSTS_VALU"] / (kernel_ms * 1e-3)
+    return {"kernel": named, "wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "achieved_per_s": rate,
+            "peak_per_s": VALU_ISSUE_PEAK, "frac": rate / VALU_ISSUE_PEAK,
+            "lane_utilisation": pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]),
+            "wait_share": pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"] if "SQ_WAIT_ANY" in pmc else None,
+            "hbm_traffic_bytes_per_launch": (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc else None,
+            "hbm_traffic_note": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md)",
+            "source": pmc_file + " (rocprofv3 --pmc of this workload) / HIP-event kernel time of this run"}
+
+
 def side_workload(deck_name, energies, sig_rough, n_slots, dev_index, pmc_file=None):
     """started photons/s of another BASELINE configuration's kernel (histogram only, one warm-up + one timed run).
-    pmc_file: committed rocprofv3 --pmc summary of exactly this workload (scripts/profile_r03.sh + scripts/side_workload.py):
-    its SQ_INSTS_VALU over the kernel time measured here is the VALU issue rate, the resource this kernel is bound by."""
+    pmc_file: committed rocprofv3 --pmc summary of exactly this workload."""
     import polycap_amd
     path = os.path.join(ROOT, "tests", "golden", "example", deck_name + ".inp")
     prob = polycap_amd.problem_from_inp(path, energies=energies, sig_rough=sig_rough)
@@ -278,49 +312,65 @@ def side_workload(deck_name, energies, sig_rough, n_slots, dev_index, pmc_file=N
         t0 = time.perf_counter()
         r = c.transmission(2, 0, n_slots)
         dt = time.perf_counter() - t0
+        kernel = c.last_kernel()
+        sweeps = c.sweep_stats() if kernel == "pc_trace_log_kernel" else None
     eff = r["efficiencies"]
     out = {"workload": "example/%s.inp, %d energies%s, %d exit photons, histogram only" %
                        (deck_name, prob.n_energies, "" if sig_rough is None else ", sig_rough %g A" % sig_rough, n_slots),
-           "started_photons_per_s": r["i_start"] / (r["kernel_ms"] * 1e-3), "kernel_ms": r["kernel_ms"], "wall_ms": dt * 1e3,
+           "started_photons_per_s": r["i_start"] / (r["kernel_ms"] * 1e-3), "kernel": kernel, "kernel_ms": r["kernel_ms"], "wall_ms": dt * 1e3,
            "n_started": r["i_start"], "n_exit": r["i_exit"], "n_energies": prob.n_energies,
            "efficiency_first_last": [float(eff[0]), float(eff[-1])],
            "constants": "synthetic away from 10 keV" if getattr(prob, "synthetic_constants", False) else "pinned"}
+    if sweeps:
+        out["sweeps"] = {"passes": sweeps["passes"], "pass_reflection_steps": sweeps["iterations"],
+                         "waves_finish_at": sweeps["wave_life_sum"] / max(1.0, float(sweeps["wave_life_max"])) / (r_waves(kernel) or 1.0)}
     if pmc_file is not None:
-        try:
-            with open(os.path.join(ROOT, pmc_file)) as f:
-                pmc = json.load(f)
-            rate = pmc["SQ_INSTS_VALU"] / (r["kernel_ms"] * 1e-3)
-            out["valu_issue"] = {"wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "achieved_per_s": rate,
-                                 "peak_per_s": VALU_ISSUE_PEAK, "frac": rate / VALU_ISSUE_PEAK,
-                                 "lane_utilisation": pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]),
-                                 "wait_share": pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"] if "SQ_WAIT_ANY" in pmc else None,
-                                 "hbm_traffic_bytes_per_launch": (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc else None,
-                                 "source": pmc_file + " (rocprofv3 --pmc of this workload) / HIP-event kernel time of this run"}
-        except Exception:
-            out["valu_issue"] = None
+        out["valu_issue"] = pmc_block(pmc_file, kernel, r["kernel_ms"])
     return out
+
+
+def r_waves(kernel):
+    """waves of a full launch of the logging kernel: one 512-thread workgroup per CU"""
+    return 256 * 8.0 if kernel == "pc_trace_log_kernel" else None
 
 
 def leak_workload(n_slots, dev_index):
     """SURVEY 8(f) rank 1, leak_calc=true: the reference's ellipsoidal test optic (tests/leaks.c), uniform illumination, 10 keV,
-    one warm-up run + one timed run; kernel time by HIP events, wall = with the events fetched and put into the reference's list
-    order on the host."""
+    one warm-up run + one timed run; kernel time by HIP events, wall = with the events in the reference's list order on the host.
+    Beside it the CPU oracle's leak driver (the reference's literal algorithm) on a bounded sample of the same slots."""
     import polycap_amd
     from polycap_amd import capi
     from polycap_amd.decks import optical_constants
     prof = capi.Profile(capi.Profile.ELLIPSOIDAL, 9., 0.2065, 0.0585, 0.00035, 9.9153e-5, 1000., 0.5)
     a, s, _ = optical_constants([8, 14], [0.53, 0.47], 2.23, [10.0])
-    prob = polycap_amd.Problem(prof.get_z(), prof.get_cap(), prof.get_ext(), 0.0, 200000, 2.23, [10.0], a, s,
-                               2000.0, 0.2065, 0.2065, -1.0, 0.0, 0.0, 0.0, 0.5)
+    source = (2000.0, 0.2065, 0.2065, -1.0, 0.0, 0.0, 0.0, 0.5)
+    prob = polycap_amd.Problem(prof.get_z(), prof.get_cap(), prof.get_ext(), 0.0, 200000, 2.23, [10.0], a, s, *source)
     with polycap_amd.TraceContext(prob, dev_index) as c:
         c.transmission(1, 0, 4096, leak_calc=True)
         t0 = time.perf_counter()
         r = c.transmission(20000, 0, n_slots, leak_calc=True)
         dt = time.perf_counter() - t0
-    return {"workload": "leak_calc=true, ellipsoidal test optic of the reference's tests/leaks.c, 10 keV, %d exit photons" % n_slots,
-            "started_photons_per_s": r["i_start"] / (r["kernel_ms"] * 1e-3), "kernel_ms": r["kernel_ms"], "wall_ms": dt * 1e3,
-            "n_started": r["i_start"], "n_exit": r["i_exit"], "extleak_events": len(r["ext"]), "intleak_events": len(r["int"]),
-            "kernel": "pc_leak_kernel<0, 1024>"}
+        kernel = c.last_kernel()
+    out = {"workload": "leak_calc=true, ellipsoidal test optic of the reference's tests/leaks.c, 10 keV, %d exit photons" % n_slots,
+           "started_photons_per_s": r["i_start"] / (r["kernel_ms"] * 1e-3), "kernel_ms": r["kernel_ms"], "wall_ms": dt * 1e3,
+           "n_started": r["i_start"], "n_exit": r["i_exit"], "extleak_events": len(r["ext"]), "intleak_events": len(r["int"]),
+           "kernel": kernel, "valu_issue": pmc_block("profiles/r04/leak_pmc_summary.json", kernel, r["kernel_ms"])}
+    try:
+        from oracle import pyoracle as O
+        affinity, quota, model = host_cpus()
+        threads = affinity if quota is None else max(1, min(affinity, int(round(quota))))
+        optic = O.Optic(prob.z, prob.cap, prob.ext, prob.sig_rough, prob.n_cap, prob.density)
+        n_cpu = 125 * threads           # ~55 started photons/s per thread: about 6 s of CPU work per thread
+        t0 = time.perf_counter()
+        o = O.transmission(optic, O.make_source(*source), [10.0], a, s, 20000, 0, n_cpu, leak_calc=True, n_threads=threads)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": o["i_start"] / dtc, "unit": "photons/s", "cores": threads, "kind": "port", "cpu_model": model,
+                               "sample": "oracle leak driver (oracle/polycap_oracle_leak.c, the reference's literal wall search) on slots "
+                                         "[0,%d) of the same workload, %.1f s on %d threads" % (n_cpu, dtc, threads),
+                               "extleak_events": int(len(o["ext"])), "intleak_events": int(len(o["int"]))}
+    except Exception as e:      # the checker is not part of the product: a leg without it still reports the device side
+        out["cpu_baseline"] = {"error": repr(e)}
+    return out
 
 
 def wall_incl_copyback(deck, n_photons, started_per_exit):

@@ -107,6 +107,9 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
  *   "log_cap"          reflections per log of the logging kernel (default 64, 1..255)
  *   "sweep_skip"       histogram-only runs of the logging kernel stop multiplying a weight once it is below 2^-64 (it adds
  *                      nothing to the exact sums any more; default 1)
+ *   "sweep_fuse"       histogram-only runs of the logging kernel: the sweep of a photon that has left the optic adds its weights
+ *                      to the sums itself, no weight row is written (default 1; 2: also for photons whose proxy energies are
+ *                      dead, which exercises the exact take-back pass; 0: off)
  *   "fetch_threads"    host threads of the staging fallback of the image fetch (0 = min(16, cores))
  *   leak runs: "leak_max_depth" (stack frames per lane = walls one photon may cross), "leak_stack_mb" (HBM for those
  *                      stacks), "leak_capacity" (leak record buffer, 0 = automatic; a run that outgrows it is repeated). */
@@ -210,13 +213,14 @@ POLYCAP_EXTERN int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6]);
  * 2 launching wave per workgroup (option "producer"; by default chosen when the photons of the context's last run made at
  * least 4 segment visits (reflections, mostly; absorbed photons included) per launch -- a first run of 2e6 slots or more is preceded by a 32768-slot probe),
  * 3 one wave per photon (experiment builds only), 4 logged reflections (pc_trace_log_kernel: source runs with more than 32
- * energies, option "batch_reflections" 1).  -1: none yet. */
+ * energies, option "batch_reflections" 1), 5 leak_calc runs (pc_leak_kernel; explicit-photon leak launches included).  -1: none yet. */
 POLYCAP_EXTERN int pc_hip_last_kernel(pc_hip_ctx *ctx);
 /* The weight sweeps of the last run when pc_trace_log_kernel traced it: stats = {wave-level passes over 64 (photon, energy)
- * pairs, wave-level (pass, reflection) iterations}; *ct_tame (optional) = the grazing cosine above which the host certified
+ * pairs, wave-level (pass, reflection) iterations, sum over the waves of their lifetimes in shader clock ticks, the longest
+ * lifetime (mean / longest = how evenly the waves finished)}; *ct_tame (optional) = the grazing cosine above which the host certified
  * every energy's reflectivity inside [0, 1 - 1e-11] (-1: no log run yet); proxies (optional) = the one or two energy indices
  * every lane follows itself (-1: none) */
-POLYCAP_EXTERN int pc_hip_sweep_stats(pc_hip_ctx *ctx, int64_t stats[2], double *ct_tame, int proxies[2]);
+POLYCAP_EXTERN int pc_hip_sweep_stats(pc_hip_ctx *ctx, int64_t stats[4], double *ct_tame, int proxies[2]);
 
 /* efficiency formula of src/polycap-source.c:1066-1076 from (summed) totals */
 POLYCAP_EXTERN void pc_hip_efficiencies(size_t n_energies, const double *sum_weights, const int64_t counters[6], double *efficiencies);

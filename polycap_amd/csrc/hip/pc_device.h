@@ -857,6 +857,68 @@ PC_HD double pc_fresnel3(double d2, double n2r, double n2i, double zi2, double c
 	return pc_div_fast(fma(fs*Ns, Dp, (fp*Np)*Ds), Ds*Dp);
 }
 
+/* N reflections of one energy at once (the FAST loop of pc_trace_log_kernel): the same operations as N calls of pc_fresnel3,
+ * written step by step for all of them so that the device compiler issues the N dependent chains alternately (its scheduler
+ * would run them one after the other; a scheduling barrier after every step keeps the order written here).  in[k] = {c, c2,
+ * fs, fp} of reflection k.  Bit-identical to the single evaluation. */
+#if PC_FAST_MATH_DEVICE
+#define PC_CHAIN_STEP() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PC_CHAIN_STEP() ((void)0)
+#endif
+template <int N>
+PC_HD void pc_fresnel3xN(double d2, double n2r, double n2i, double zi2, const double (&in)[N][4], double (&rt)[N])
+{
+#if PC_FAST_MATH_DEVICE
+#define PC_EACH(expr) _Pragma("unroll") for (int k = 0; k < N; k++) { expr; } PC_CHAIN_STEP()
+	double zr[N], m2[N], y[N], g[N], h[N], r[N], Q[N], S[N], cS[N], Gr[N], Gi[N], Ns[N], Ds[N], A[N], B[N], Np[N], Dp[N], t1[N], t2[N];
+	PC_EACH(zr[k] = in[k][1] - d2);
+	PC_EACH(m2[k] = fma(zr[k], zr[k], zi2));
+	PC_EACH(y[k] = __builtin_amdgcn_rsq(m2[k]));
+	PC_EACH(g[k] = m2[k]*y[k]);
+	PC_EACH(h[k] = 0.5*y[k]);
+	PC_EACH(r[k] = fma(-h[k], g[k], 0.5));
+	PC_EACH(g[k] = fma(g[k], r[k], g[k]));                   /* |z| */
+	PC_EACH(Q[k] = g[k] + fabs(zr[k]));
+	PC_EACH(m2[k] = Q[k] + Q[k]);
+	PC_EACH(y[k] = __builtin_amdgcn_rsq(m2[k]));
+	PC_EACH(g[k] = m2[k]*y[k]);
+	PC_EACH(h[k] = 0.5*y[k]);
+	PC_EACH(r[k] = fma(-h[k], g[k], 0.5));
+	PC_EACH(S[k] = fma(g[k], r[k], g[k]));
+	PC_EACH(cS[k] = in[k][0]*S[k]);
+	PC_EACH(Gr[k] = (zr[k] >= 0.) ? Q[k] : n2i);
+	PC_EACH(Gi[k] = (zr[k] >= 0.) ? n2i : Q[k]);
+	PC_EACH(g[k] = cS[k] - Gr[k]);                           /* nr */
+	PC_EACH(h[k] = cS[k] + Gr[k]);                           /* dr */
+	PC_EACH(r[k] = Gi[k]*Gi[k]);
+	PC_EACH(Ns[k] = fma(g[k], g[k], r[k]));
+	PC_EACH(Ds[k] = fma(h[k], h[k], r[k]));
+	PC_EACH(A[k] = n2r*cS[k]);
+	PC_EACH(B[k] = n2i*cS[k]);
+	PC_EACH(g[k] = A[k] - Gr[k]);                            /* pr */
+	PC_EACH(h[k] = B[k] - Gi[k]);                            /* pi */
+	PC_EACH(A[k] = A[k] + Gr[k]);                            /* er */
+	PC_EACH(B[k] = B[k] + Gi[k]);                            /* ei */
+	PC_EACH(h[k] = h[k]*h[k]);
+	PC_EACH(Np[k] = fma(g[k], g[k], h[k]));
+	PC_EACH(B[k] = B[k]*B[k]);
+	PC_EACH(Dp[k] = fma(A[k], A[k], B[k]));
+	PC_EACH(t1[k] = in[k][2]*Ns[k]);
+	PC_EACH(t2[k] = in[k][3]*Np[k]);
+	PC_EACH(t2[k] = t2[k]*Ds[k]);
+	PC_EACH(t1[k] = fma(t1[k], Dp[k], t2[k]));               /* numerator */
+	PC_EACH(m2[k] = Ds[k]*Dp[k]);                            /* denominator */
+	PC_EACH(y[k] = __builtin_amdgcn_rcp(m2[k]));
+	PC_EACH(r[k] = fma(-m2[k], y[k], 1.0));
+	PC_EACH(y[k] = fma(y[k], r[k], y[k]));
+	PC_EACH(rt[k] = t1[k]*y[k]);
+#undef PC_EACH
+#else
+	for (int k = 0; k < N; k++) rt[k] = pc_fresnel3(d2, n2r, n2i, zi2, in[k][0], in[k][1], in[k][2], in[k][3]);
+#endif
+}
+
 /* one energy of one reflection in FORM 3, the roughness factor per reflection as the reference applies it (:626-627).
  * Same return values as pc_reflect_energy_f. */
 PC_HD int pc_reflect_energy3(const pc_energy_const &ec, double c, double c2, double fs, double fp, double &w)

@@ -125,6 +125,7 @@ struct pc_kargs {
 	int n_proxy, proxy_e[2];      /* energies whose weights every lane carries itself (pc_sweep_certificate) */
 	int flush_min;                /* photons of a wave that wait for a sweep before one is run for them alone */
 	int sweep_skip;               /* histogram-only runs: a weight below 2^-64 is not multiplied any further */
+	int sweep_fuse;               /* histogram-only runs: the sweep of a finished photon adds its weights to the sums itself (2: whatever its proxies say -- tests) */
 	double ct_tame;               /* a reflection with cos theta >= ct_tame has 0 <= rtot < 1 - 1e-11 at every energy of the run */
 	/* explicit-photon mode */
 	const double *in_start, *in_dir, *in_elecv;
@@ -913,6 +914,8 @@ struct pc_hip_ctx {
 	                                * (pc_sweep_kernel.h), 0 = every reflection sweeps the weights at once */
 	int log_cap = 64;              /* option "log_cap": reflections per log of pc_trace_log_kernel */
 	int sweep_skip = 1;            /* option "sweep_skip": histogram-only log runs stop multiplying a weight below 2^-64 */
+	int sweep_fuse = 1;            /* option "sweep_fuse": histogram-only log runs add a finished photon's weights to the sums in its sweep; 2 = also when
+	                                * its proxies are dead, so that photons the sweep finds dead exercise the take-back pass (tests) */
 	double *d_rlog = nullptr;
 	size_t rlog_elems = 0;
 	int sweep_cert = 0;            /* pc_sweep_certificate has run */
@@ -1109,7 +1112,7 @@ static void pc_sweep_certificate(pc_hip_ctx *ctx)
  * constants fit in LDS beside a stage of at least one log per wave; returns the stage size (doubles per wave), 0 if not */
 static size_t pc_log_stage_doubles(const pc_hip_ctx *ctx, int ne, int log_cap)
 {
-	const size_t fixed = 4*PCS_PITCH*sizeof(double) + PCS_PITCH*sizeof(pc_marg4) + pcs_dyn_lds((size_t)ne, PCS_BLOCK, 0);
+	const size_t fixed = 6*PCS_PITCH*sizeof(double) + PCS_PITCH*sizeof(pc_marg4) + pcs_dyn_lds((size_t)ne, PCS_BLOCK, 0);
 	if (fixed >= 163840) return 0;
 	size_t per_wave = ((163840 - fixed)/(PCS_BLOCK/PC_WAVE))/sizeof(double);
 	const size_t one = PCS_ENT*(size_t)log_cap;
@@ -1258,6 +1261,7 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 			a.n_proxy = ctx->sweep_n_proxy; a.proxy_e[0] = ctx->sweep_proxy_e[0]; a.proxy_e[1] = ctx->sweep_proxy_e[1];
 			a.ct_tame = ctx->sweep_ct_tame;
 			a.sweep_skip = (ctx->sweep_skip && !a.keep_images) ? 1 : 0;
+			a.sweep_fuse = a.keep_images ? 0 : ctx->sweep_fuse;
 			if (ctx->rec_ev0) PC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
 			hipLaunchKernelGGL((pc_trace_log_kernel<MODE>), dim3(grid), dim3(PCS_BLOCK), pcs_dyn_lds((size_t)ne, PCS_BLOCK, stage), ctx->stream, a);
 			ctx->last_kernel = 4;
@@ -1433,6 +1437,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "batch_reflections") ctx->batch_reflections = value ? 1 : 0;
 	else if (n == "log_cap") { if (value < 1 || value > 255) return pc_fail(PC_HIP_ERR_INVALID, "log_cap must be in [1,255]"); ctx->log_cap = (int)value; }
 	else if (n == "sweep_skip") ctx->sweep_skip = value ? 1 : 0;
+	else if (n == "sweep_fuse") { if (value < 0 || value > 2) return pc_fail(PC_HIP_ERR_INVALID, "sweep_fuse must be 0, 1 or 2"); ctx->sweep_fuse = (int)value; }
 	else if (n == "plane_images") ctx->plane_images = value ? 1 : 0;
 	else if (n == "compact_images") ctx->compact_images = value ? 1 : 0;
 	else if (n == "slot_ids") ctx->slot_ids = value ? 1 : 0;
@@ -1963,7 +1968,7 @@ int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6])
 	return PC_HIP_OK;
 }
 
-int pc_hip_sweep_stats(pc_hip_ctx *ctx, int64_t stats[2], double *ct_tame, int proxies[2])
+int pc_hip_sweep_stats(pc_hip_ctx *ctx, int64_t stats[4], double *ct_tame, int proxies[2])
 {
 	if (!ctx || !stats) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_sweep_stats: NULL argument");
 	int st = pc_hip_transmission_wait(ctx, nullptr);
@@ -1973,6 +1978,8 @@ int pc_hip_sweep_stats(pc_hip_ctx *ctx, int64_t stats[2], double *ct_tame, int p
 	const bool log_run = ctx->last_kernel == 4;
 	stats[0] = log_run ? (int64_t)t.phase[6] : 0;
 	stats[1] = log_run ? (int64_t)t.phase[7] : 0;
+	stats[2] = log_run ? (int64_t)t.counters[6] : 0;
+	stats[3] = log_run ? (int64_t)t.counters[7] : 0;
 	if (ct_tame) *ct_tame = ctx->sweep_cert ? ctx->sweep_ct_tame : -1.;
 	if (proxies) { proxies[0] = ctx->sweep_cert ? ctx->sweep_proxy_e[0] : -1; proxies[1] = (ctx->sweep_cert && ctx->sweep_n_proxy > 1) ? ctx->sweep_proxy_e[1] : -1; }
 	return PC_HIP_OK;

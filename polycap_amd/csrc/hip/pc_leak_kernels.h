@@ -438,6 +438,7 @@ static int pc_leak_enqueue(pc_hip_ctx *ctx, pc_kargs &a, long long n_items, long
 	else
 		hipLaunchKernelGGL((pc_leak_kernel<MODE, PC_MAX_PITCH>), dim3(grid), dim3(PC_LEAK_BLOCK), 0, ctx->stream, a, lk);
 	PC_HIP_CHECK(hipGetLastError());
+	ctx->last_kernel = 5;
 	PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
 	return PC_HIP_OK;
 }

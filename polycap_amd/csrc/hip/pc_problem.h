@@ -54,6 +54,9 @@ static inline int pc_build_tables(const pc_hip_problem *p, pc_host_tables &t, st
 	pm.mono = (pm.n_shells == 0.) ? 1 : 0;
 	pm.n_energies = (int)p->n_energies;
 	pm.literal = 0;
+	/* which Fresnel form a run evaluates depends on where its weights live (pc_launch_kernel): registers for 1, up to 4 and up to 8
+	 * energies on profiles of up to 1024 points (FORMs 0 / 1), memory otherwise (FORM 3) */
+	pm.form3 = (p->n_energies > 1 && !(p->n_energies <= 8 && p->nmax + 1 <= 1024)) ? 1 : 0;
 	pm.hexscale = 2.*PC_COSPI_6*(pm.n_shells + 1);
 	pm.inv_hexscale = 1.0/pm.hexscale;
 	pm.uniform_illum = (p->src_sigx < 0. || p->src_sigy < 0.) ? 1 : 0;

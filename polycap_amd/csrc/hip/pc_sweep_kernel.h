@@ -41,24 +41,29 @@
  *     hundred photons and the others none: the sweeps, 92 % of the work, are as efficient for one photon as for sixty-four.
  */
 #ifndef PCS_BLOCK
-#define PCS_BLOCK 768          /* 12 waves per CU, 3 per SIMD */
+#define PCS_BLOCK 512          /* 8 waves per CU, 2 per SIMD: 256 registers per lane (at 3 per SIMD and 168 registers a hundred of them lived in
+                                * scratch, on the path of every EVENT phase: 28.9 against 28.2 ms at 291 energies, 18.1 against 15.4 ms at 100:
+                                * profiles/r04/kernel_history.md); the sweeps keep the SIMD busy with two interleaved chains per wave */
 #endif
 #ifndef PCS_WAVES
-#define PCS_WAVES 3
+#define PCS_WAVES 2
 #endif
 #define PCS_PITCH 1024
 #define PCS_MAXPS 16           /* photons of a wave swept in one round (their logs are staged in LDS) */
 #define PCS_ENT 4              /* doubles of a staged log entry: cos, cos^2, fs, fp */
 #define PCS_DEAD 5.421010862427522e-20    /* 2^-64 */
+#ifndef PCS_CHAINS
+#define PCS_CHAINS 2           /* reflections the FAST loop takes per step (pc_fresnel3xN: that many interleaved chains) */
+#endif
 #ifndef PCS_LEASH
 #define PCS_LEASH 4            /* reflections between sweeps of a photon whose proxies are dead but which a sweep found alive */
 #endif
 
-/* dynamic LDS of pc_trace_log_kernel: exact sums, per-energy constants (5 fields), proxy weights (2 per lane), per wave the
- * sweep tables (4 x 16 words + 16 doubles) and `stage` doubles of staged logs */
+/* dynamic LDS of pc_trace_log_kernel: exact sums, per-energy constants (5 fields), per wave the sweep tables (4 x 16 words +
+ * 16 doubles) and `stage` doubles of staged logs */
 static size_t pcs_dyn_lds(size_t ne, int block, size_t stage_doubles_per_wave)
 {
-	return 2*ne*sizeof(unsigned long long) + 5*ne*sizeof(double) + 2*(size_t)block*sizeof(double)
+	return 2*ne*sizeof(unsigned long long) + 5*ne*sizeof(double)
 	     + (size_t)(block/PC_WAVE)*(4*PCS_MAXPS*sizeof(unsigned int) + PCS_MAXPS*sizeof(double) + stage_doubles_per_wave*sizeof(double));
 }
 
@@ -67,12 +72,13 @@ __global__ void __launch_bounds__(PCS_BLOCK, PCS_WAVES)
 pc_trace_log_kernel(pc_kargs a)
 {
 	static_assert(MODE != PC_MODE_EXPLICIT, "the log kernel serves source runs");
-	__shared__ double lds[4*PCS_PITCH];
+	__shared__ double lds[6*PCS_PITCH];
 	__shared__ pc_marg4 ldsg[PCS_PITCH];
 	extern __shared__ unsigned long long l_acc[];
 	const pc_params &Pm = a.pm;
 	const int npts = Pm.nmax + 1, ne = Pm.n_energies;
 	double *l_z = lds, *l_cap = lds + PCS_PITCH, *l_zh = lds + 2*PCS_PITCH, *l_cap2 = lds + 3*PCS_PITCH;
+	double *l_hexd = lds + 4*PCS_PITCH, *l_idz = lds + 5*PCS_PITCH;
 	/* per-energy constants of FORM 3 in LDS: d2, Re n^2, Im n^2, zi2 (fields 0-3 of ec_soa) and rough_c^2 (field 6) */
 	double *const ecs = (double *)(l_acc + 2*ne);
 	for (int k = threadIdx.x; k < npts; k += blockDim.x) {
@@ -80,6 +86,8 @@ pc_trace_log_kernel(pc_kargs a)
 		l_cap[k] = a.g_cap[k];
 		l_zh[k] = a.g_zh[k];
 		l_cap2[k] = a.g_cap2[k];
+		l_hexd[k] = a.g_hexd[k];
+		l_idz[k] = a.g_idz[k];
 		ldsg[k] = a.g_mg[k];
 	}
 	for (int k = threadIdx.x; k < 2*ne; k += blockDim.x) l_acc[k] = 0ull;
@@ -88,7 +96,7 @@ pc_trace_log_kernel(pc_kargs a)
 	__syncthreads();
 	pc_tables T;
 	T.z = l_z; T.cap = l_cap; T.zh = l_zh; T.cap2 = l_cap2; T.ext = a.g_ext;
-	T.hexd = a.g_hexd; T.idz = a.g_idz;          /* read by the EVENT phase only: global (L2-resident) */
+	T.hexd = l_hexd; T.idz = l_idz;              /* read once per flight and per segment visit: on the path of a lone photon at the end of a launch */
 	T.mg = ldsg;
 	const long long ws = a.img_ws;
 	const int lane = threadIdx.x & (PC_WAVE - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -96,14 +104,15 @@ pc_trace_log_kernel(pc_kargs a)
 	const long long wave_gtid0 = gtid - lane;
 	const long long grid_waves = (long long)gridDim.x * nwaves;
 	const int K = a.log_cap, PS = a.stage_ps;
-	double *const l_prox = ecs + 5*ne + 2*threadIdx.x;
-	double *const l_csum = ecs + 5*ne + 2*blockDim.x + wave*PCS_MAXPS;     /* per staged photon: sum of cos^2 over its log */
-	unsigned int *const l_tab = (unsigned int *)(ecs + 5*ne + 2*blockDim.x + nwaves*PCS_MAXPS);
+	double *const l_csum = ecs + 5*ne + wave*PCS_MAXPS;     /* per staged photon: sum of cos^2 over its log */
+	unsigned int *const l_tab = (unsigned int *)(ecs + 5*ne + nwaves*PCS_MAXPS);
 	unsigned int *const map = l_tab + wave*(4*PCS_MAXPS), *const vflag = map + PCS_MAXPS, *const vcnt = map + 2*PCS_MAXPS, *const vbad = map + 3*PCS_MAXPS;
 	double *const stage = (double *)(l_tab + nwaves*(4*PCS_MAXPS)) + (size_t)wave*(size_t)(PS*K*PCS_ENT);
 	double *const my_log = a.rlog + gtid*(long long)(3*K);
 	const int rough = a.sweep_rough;
 	const bool skip = a.sweep_skip != 0;
+
+	const unsigned long long t_begin = __builtin_readcyclecounter();   /* s_memtime: how evenly the waves finish (pc_hip_sweep_stats) */
 
 	pc_photon<0> ph;
 	ph.wmem = nullptr; ph.wstride = 1; ph.wset = 0; ph.rc = 0;
@@ -112,6 +121,12 @@ pc_trace_log_kernel(pc_kargs a)
 	int npend = 0;                /* reflections in this lane's log */
 	int lim = K;                  /* the log is swept when it holds this many: K while a proxy is alive */
 	int untame = 0;               /* the log holds a reflection that is not tame: EXACT sweep */
+	double wprox0 = 1.0, wprox1 = 1.0;   /* the proxy energies' weights of this lane's photon */
+	int okpre = -1;               /* exit-window test of a finished photon made ahead of its sweep (-1: not made) */
+	int summed = 0;               /* the sweep has added the finished photon's weights to the sums itself (fused finalisation) */
+	int fresh = 0;                /* the last EVENT phase left a reflection's raw numbers (cos theta, (E.s)^2, |n x d|^2) in fr_*: fractions, log entry,
+	                               * tameness and proxies are due (the bookkeeping step at the top of the loop) */
+	double fr_c = 0., fr_es2 = 0., fr_sd2 = 0.;
 	long long slot = -1;
 	unsigned int attempt = 0;
 	double cosalpha0 = 0.;
@@ -124,8 +139,17 @@ pc_trace_log_kernel(pc_kargs a)
 		const int mine = (int)((mR >> lane) & 1ull);
 		const int rank = __popcll(mR & ((1ull << lane) - 1ull));
 		const int nP = __popcll(mR);
+		/* Fused finalisation (histogram-only runs): a photon that has reached the end of the optic inside the exit window, whose log
+		 * is tame and one of whose proxies is alive, is alive at the end of its log, so the sweep adds its weights to the exact sums
+		 * itself -- no weight row is written for it and none read back by the NEW phase.  Should the sweep find it dead all the
+		 * same (a proxy that differs from the sweep's weight in the last bit), a second pass takes the sums back exactly. */
+		int fin = 0;
+		if (mine && state == LS_DONE && ph.rc == 1) {
+			okpre = pc_in_exit_window(Pm, ph);
+			fin = (okpre && a.sweep_fuse && !untame && (lim == K || a.sweep_fuse > 1)) ? 1 : 0;
+		}
 		if (mine) {
-			map[rank] = (unsigned)lane | (ph.wset ? 0x40u : 0u) | (untame ? 0x80u : 0u) | ((unsigned)npend << 8);
+			map[rank] = (unsigned)lane | (ph.wset ? 0x40u : 0u) | (untame ? 0x80u : 0u) | ((unsigned)npend << 8) | (fin ? 0x10000u : 0u);
 			vflag[rank] = 0u; vcnt[rank] = 0u; vbad[rank] = 255u;
 		}
 		/* the lanes' log entries (global stores of the EVENT phases) have arrived; the tables above are visible to the wave */
@@ -133,7 +157,7 @@ pc_trace_log_kernel(pc_kargs a)
 		__builtin_amdgcn_wave_barrier();
 		for (int qq = 0; qq < nP; qq++) {
 			const unsigned info = map[qq];
-			const int n = (int)(info >> 8);
+			const int n = (int)((info >> 8) & 255u);
 			const double *src = a.rlog + (wave_gtid0 + (long long)(info & 63u))*(long long)(3*K);
 			double *dst = stage + qq*(PCS_ENT*K);
 			double part = 0.;
@@ -152,14 +176,21 @@ pc_trace_log_kernel(pc_kargs a)
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		const int total = nP*ne;
+		for (int rep = 0; rep < 2; rep++) {
+		const bool undo = rep != 0;
 		int q = 0, e = lane;
 		while (e >= ne) { e -= ne; q++; }
 		for (int base = 0; base < total; base += PC_WAVE) {
-			const bool act = base + lane < total;
+			bool act = base + lane < total;
+			if (undo) {
+				/* only the photons whose sums have to be taken back */
+				act = act && vflag[q] == 2u;
+				if (__builtin_amdgcn_ballot_w64(act) == 0ull) { e += PC_WAVE; while (e >= ne) { e -= ne; q++; } continue; }
+			}
 			const int qc = act ? q : 0, ee = act ? e : 0;
 			const unsigned info = map[qc];
 			const int p = (int)(info & 63u);
-			const int n = act ? (int)(info >> 8) : 0;
+			const int n = act ? (int)((info >> 8) & 255u) : 0;
 			const bool exact = act && (info & 0x80u);
 			double *const wrow = a.wscratch + (wave_gtid0 + p)*(long long)ne + ee;
 			double w = 1.0;
@@ -173,13 +204,30 @@ pc_trace_log_kernel(pc_kargs a)
 			bool alive;
 			st_pass++;
 			if (__builtin_amdgcn_ballot_w64(exact) == 0ull) {
-				/* FAST: every reflection of these logs is tame */
+				/* FAST: every reflection of these logs is tame.  A pass whose items all belong to logs of one length (one photon,
+				 * nearly always) runs two reflections per step: two independent Fresnel chains for the fp64 pipe */
 				int r = 0;
-				for (; r < n_pass; r++) {
-					if (skip && (r & 7) == 7 && __builtin_amdgcn_ballot_w64(r < n && w >= PCS_DEAD) == 0ull) break;
-					if (r < n) {
-						const double f = pc_fresnel3(d2, n2r, n2i, zi2, gq[PCS_ENT*r], gq[PCS_ENT*r + 1], gq[PCS_ENT*r + 2], gq[PCS_ENT*r + 3]);
-						w = w*f;
+				if (PCS_CHAINS > 1 && __builtin_amdgcn_ballot_w64(act && n != n_pass) == 0ull) {
+					for (; r + PCS_CHAINS <= n_pass; r += PCS_CHAINS) {
+						if (skip && (r & 7) + PCS_CHAINS > 7 && __builtin_amdgcn_ballot_w64(act && w >= PCS_DEAD) == 0ull) break;
+						double in[PCS_CHAINS][4], f[PCS_CHAINS];
+#pragma unroll
+						for (int k = 0; k < PCS_CHAINS; k++) {
+							in[k][0] = gq[PCS_ENT*(r + k)]; in[k][1] = gq[PCS_ENT*(r + k) + 1]; in[k][2] = gq[PCS_ENT*(r + k) + 2]; in[k][3] = gq[PCS_ENT*(r + k) + 3];
+						}
+						pc_fresnel3xN<PCS_CHAINS>(d2, n2r, n2i, zi2, in, f);
+#pragma unroll
+						for (int k = 0; k < PCS_CHAINS; k++) w = w*f[k];
+					}
+					for (; r < n_pass; r++)
+						w = w*pc_fresnel3(d2, n2r, n2i, zi2, gq[PCS_ENT*r], gq[PCS_ENT*r + 1], gq[PCS_ENT*r + 2], gq[PCS_ENT*r + 3]);
+				} else {
+					for (; r < n_pass; r++) {
+						if (skip && (r & 7) == 7 && __builtin_amdgcn_ballot_w64(r < n && w >= PCS_DEAD) == 0ull) break;
+						if (r < n) {
+							const double f = pc_fresnel3(d2, n2r, n2i, zi2, gq[PCS_ENT*r], gq[PCS_ENT*r + 1], gq[PCS_ENT*r + 2], gq[PCS_ENT*r + 3]);
+							w = w*f;
+						}
 					}
 				}
 				st_iter += (unsigned long long)r;
@@ -209,9 +257,24 @@ pc_trace_log_kernel(pc_kargs a)
 				}
 				alive = act && (cnt == (unsigned)n);
 			}
-			if (act) *wrow = w;
+			if (act) {
+				if (info & 0x10000u) {
+					const unsigned long long f = (unsigned long long)(w * PC_FIX_SCALE);
+					if (f) {
+						if (!undo) {
+							const unsigned long long old = atomicAdd(&l_acc[2*ee], f);
+							if (old + f < old) atomicAdd(&l_acc[2*ee + 1], 1ull);
+						} else {
+							const unsigned long long old = atomicSub(&l_acc[2*ee], f);
+							if (old < f) atomicSub(&l_acc[2*ee + 1], 1ull);
+						}
+					}
+				} else {
+					*wrow = w;
+				}
+			}
 			/* one lane per photon of the pass reports "some energy of these is alive at the end of the log" */
-			{
+			if (!undo) {
 				const unsigned long long mK = __builtin_amdgcn_ballot_w64(alive);
 				const int q_left = __shfl_up(qc, 1, PC_WAVE);
 				if (act && (lane == 0 || q_left != qc)) {
@@ -225,7 +288,17 @@ pc_trace_log_kernel(pc_kargs a)
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
+		if (undo) break;
+		/* a fused photon the sweep found dead: its sums are taken back by a second pass over its items */
+		const bool back = mine && fin && vflag[rank] == 0u;
+		if (back) vflag[rank] = 2u;
+		if (__builtin_amdgcn_ballot_w64(back) == 0ull) break;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		}
 		if (mine) {
+			if (fin) summed = (vflag[rank] == 1u) ? 1 : 0;
+			if (vflag[rank] == 2u) vflag[rank] = 0u;
 			if (untame) {
 				/* first logged reflection that ends the photon: an error at any energy (rc -1), or no energy left above 1e-4 (rc 0) */
 				const unsigned c = vcnt[rank], b = vbad[rank];
@@ -235,7 +308,7 @@ pc_trace_log_kernel(pc_kargs a)
 				state = LS_DONE; ph.rc = 0;
 			}
 			npend = 0; untame = 0;
-			ph.wset = 1;
+			if (!fin) ph.wset = 1;
 			if (lim < K) lim = (PCS_LEASH < K) ? PCS_LEASH : K;       /* proxies dead, photon swept: a longer leash from here on */
 		}
 	};
@@ -249,6 +322,36 @@ pc_trace_log_kernel(pc_kargs a)
 	};
 
 	for (;;) {
+		if (__builtin_amdgcn_ballot_w64(fresh != 0) != 0ull) {
+			if (fresh) {
+				fresh = 0;
+				double *gq = my_log + 3*npend;
+				pc_refl_geom g;
+				g.alfa = fr_c; g.es2 = fr_es2; g.sd2 = fr_sd2; g.ep2 = fr_sd2 - fr_es2; g.st2 = 0.;
+				double c2, fs, fp;
+				pc_refl_geom3(g, c2, fs, fp);
+				gq[0] = fr_c; gq[1] = fs; gq[2] = fp;
+				npend++;
+				/* tame: cos theta above the host's certificate, fractions as the geometry makes them (fs in [0, 1], fp = 1 - fs to
+				 * rounding).  NaNs fail every comparison. */
+				if (!(fr_c >= a.ct_tame && fr_c <= 1.0 && fs >= 0. && fs <= 1.0000001 && fp >= -1.e-7 && fp <= 1.0000001)) untame = 1;
+				if (lim == K) {
+					{
+						const int pe = a.proxy_e[0];
+						double f = pc_fresnel3(ecs[pe], ecs[ne + pe], ecs[2*ne + pe], ecs[3*ne + pe], fr_c, c2, fs, fp);
+						if (rough) f = f*pc_exp_neg_fast(-(ecs[4*ne + pe]*c2));
+						wprox0 = wprox0*f;
+					}
+					if (a.n_proxy > 1) {
+						const int pe = a.proxy_e[1];
+						double f = pc_fresnel3(ecs[pe], ecs[ne + pe], ecs[2*ne + pe], ecs[3*ne + pe], fr_c, c2, fs, fp);
+						if (rough) f = f*pc_exp_neg_fast(-(ecs[4*ne + pe]*c2));
+						wprox1 = wprox1*f;
+					}
+					if (!(wprox0 >= 1.e-4 || (a.n_proxy > 1 && wprox1 >= 1.e-4))) lim = 1;
+				}
+			}
+		}
 		/* sweeps: a lane whose log has reached its limit cannot reflect again (it waits at its next wall); a finished photon is
 		 * swept before the NEW phase finalises it.  Those who wait are swept together once there are a.flush_min of them (a pass
 		 * takes 64 (photon, energy) pairs: few energies want company), when the NEW phase is due for a finished one among them,
@@ -307,26 +410,10 @@ pc_trace_log_kernel(pc_kargs a)
 				state = pc_event_post(Pm, ph, h, (pend == 1) ? 1 : -1);
 			}
 			if (pend == 1) {
-				double c2, fs, fp;
-				pc_refl_geom3(g, c2, fs, fp);
-				double *gq = my_log + 3*npend;
-				gq[0] = g.alfa; gq[1] = fs; gq[2] = fp;
-				npend++;
-				/* tame: cos theta above the host's certificate, fractions as the geometry makes them (fs in [0, 1], fp = 1 - fs to
-				 * rounding).  NaNs fail every comparison. */
-				if (!(g.alfa >= a.ct_tame && g.alfa <= 1.0 && fs >= 0. && fs <= 1.0000001 && fp >= -1.e-7 && fp <= 1.0000001)) untame = 1;
-				if (lim == K) {
-					bool up = false;
-					for (int k = 0; k < a.n_proxy; k++) {
-						const int pe = a.proxy_e[k];
-						double f = pc_fresnel3(ecs[pe], ecs[ne + pe], ecs[2*ne + pe], ecs[3*ne + pe], g.alfa, c2, fs, fp);
-						if (rough) f = f*pc_exp_neg_fast(-(ecs[4*ne + pe]*c2));
-						const double wp = l_prox[k]*f;
-						l_prox[k] = wp;
-						up = up || (wp >= 1.e-4);
-					}
-					if (!up) lim = 1;
-				}
+				/* the reflection's numbers wait for the bookkeeping step at the top of the loop (fractions, log entry, tameness,
+				 * proxies): the EVENT phase is where registers are scarcest */
+				fr_c = g.alfa; fr_es2 = g.es2; fr_sd2 = g.sd2;
+				fresh = 1;
 			}
 		} else if (phase == 2) {
 			st_new += 1; st_new_l += (unsigned)nN;
@@ -340,7 +427,7 @@ pc_trace_log_kernel(pc_kargs a)
 				const int rc = ph.rc;
 				if (rc == 0) f_not_trans = 1;
 				else if (rc == 2) f_not_entered = 1;
-				else if (rc == 1) ok = pc_in_exit_window(Pm, ph);
+				else if (rc == 1) ok = (okpre >= 0) ? okpre : pc_in_exit_window(Pm, ph);
 			}
 			const bool compact = a.keep_images && a.img_cursor != nullptr;
 			unsigned long long c_base = 0ull;
@@ -358,7 +445,7 @@ pc_trace_log_kernel(pc_kargs a)
 				if (ok) {
 					f_exit = 1;
 					f_irefl = (unsigned int)ph.irefl;
-					coop = 1;    /* sums and image weights: the cooperative sweep below */
+					coop = summed ? 0 : 1;    /* sums and image weights: the cooperative sweep below, unless the photon's sweep has added them */
 					if (a.keep_images) {
 						/* src/polycap-source.c:900-923 */
 						if (compact) {
@@ -447,8 +534,8 @@ pc_trace_log_kernel(pc_kargs a)
 				pc_start s;
 				pc_sample_photon<MODE == PC_MODE_SRC_GENERIC>(Pm, a.seed, (unsigned long long)(a.slot0 + slot), attempt, s);
 				state = pc_launch_init(T, Pm, ph, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez);
-				npend = 0; untame = 0; lim = K;
-				l_prox[0] = 1.0; l_prox[1] = 1.0;
+				npend = 0; untame = 0; lim = K; okpre = -1; summed = 0;
+				wprox0 = 1.0; wprox1 = 1.0;
 				if (state == LS_MARCH) {
 					cosalpha0 = s.ex*s.dx + s.ey*s.dy + s.ez*s.dz;
 					if (a.keep_images) {
@@ -489,5 +576,8 @@ pc_trace_log_kernel(pc_kargs a)
 		atomicAdd(&a.totals->phase[2], st_event); atomicAdd(&a.totals->phase[3], st_event_l);
 		atomicAdd(&a.totals->phase[4], st_new); atomicAdd(&a.totals->phase[5], st_new_l);
 		atomicAdd(&a.totals->phase[6], st_pass); atomicAdd(&a.totals->phase[7], st_iter);
+		const unsigned long long life = __builtin_readcyclecounter() - t_begin;
+		atomicAdd(&a.totals->counters[6], life);
+		atomicMax(&a.totals->counters[7], life);
 	}
 }

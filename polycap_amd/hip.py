@@ -150,7 +150,7 @@ class TraceContext:
                     failed_slots=int(cnt[4]), launches=int(cnt[5]), i_start=int(cnt[0] + cnt[1] + cnt[2]))
 
     KERNELS = {0: "pc_trace_kernel", 1: "pc_trace_pool_kernel", 2: "pc_trace_producer_kernel", 3: "pc_trace_wave_kernel",
-               4: "pc_trace_log_kernel"}
+               4: "pc_trace_log_kernel", 5: "pc_leak_kernel"}
 
     def last_kernel(self):
         """Name of the kernel that traced the last source run (None before the first)."""
@@ -169,13 +169,14 @@ class TraceContext:
     def sweep_stats(self):
         """Weight sweeps of the last run of the logging many-energy kernel: wave-level passes and (pass, reflection) iterations,
         the host's tameness threshold and the proxy energies."""
-        st = np.zeros(2, dtype=np.int64)
+        st = np.zeros(4, dtype=np.int64)
         ct = C.c_double(0.)
         pr = (C.c_int * 2)(-1, -1)
         rc = self._L.pc_hip_sweep_stats(self._h, st.ctypes.data_as(c_int64_p), C.byref(ct), pr)
         if rc != _cabi.PC_HIP_OK:
             raise HipError("pc_hip_sweep_stats", rc)
-        return dict(passes=int(st[0]), iterations=int(st[1]), ct_tame=float(ct.value), proxies=[int(pr[0]), int(pr[1])])
+        return dict(passes=int(st[0]), iterations=int(st[1]), ct_tame=float(ct.value), proxies=[int(pr[0]), int(pr[1])],
+                    wave_life_sum=int(st[2]), wave_life_max=int(st[3]))
 
     def images(self, first=0, count=None):
         """Image data of slots [first, first+count) of the last run: images [count, 17] (the planes of pc_hip_images in

@@ -38,6 +38,18 @@ for deck, sig, ne in (("xos1", None, 291), ("ellip_l9", 5.0, 291), ("xos1", None
                         print("   weights differ by at most %.2e relative" % np.nanmax(d))
                         assert np.nanmax(d) < 1e-13
                     assert np.array_equal(out[0]["images"], out[b]["images"], equal_nan=True), (deck, b)
+        # the take-back pass of the fused finalisation: fuse photons whatever their proxies say
+        ctx.set_option("batch_reflections", 0)
+        ref = ctx.transmission(78, 0, n_check)
+        ctx.set_option("batch_reflections", 1)
+        for fuse in (0, 2, 1):
+            ctx.set_option("sweep_fuse", fuse)
+            got = ctx.transmission(78, 0, n_check)
+            assert np.array_equal(ref["counters"][:6], got["counters"][:6]), (deck, fuse)
+            if sig is None:
+                assert np.array_equal(ref["sumw_fixed"], got["sumw_fixed"]), (deck, fuse)
+            else:
+                assert np.abs(ref["sum_weights"]/got["sum_weights"] - 1.0).max() < 1e-14, (deck, fuse)
         print(deck, ne, "bit-identical", ctx.sweep_stats())
         for b in (1,):
             ctx.set_option("batch_reflections", b)

@@ -12,10 +12,10 @@ with polycap_amd.TraceContext(prob) as ctx:
     for k, v in opts:
         ctx.set_option(k, int(v))
     ctx.transmission(1, 0, 20000)
-    for cap in (32, 64, 128):
+    for cap in (64,):
         ctx.set_option("log_cap", cap)
-        for n in (250000, 1000000, 4000000):
+        for n in (100000, 250000, 500000, 1000000, 2000000, 4000000):
             r = ctx.transmission(2, 0, n)
             st = ctx.sweep_stats()
-            print("%s log_cap %3d: %8d slots, kernel %8.2f ms = %6.2f ms per 1e6 slots, %.4g started photons/s; passes %.3g iterations %.3g"
-                  % (deck, cap, n, r["kernel_ms"], r["kernel_ms"]*1e6/n, r["i_start"]/(r["kernel_ms"]*1e-3), st["passes"], st["iterations"]), flush=True)
+            print("%s log_cap %3d: %8d slots, kernel %8.2f ms = %6.2f ms per 1e6 slots, %.4g started photons/s; passes %.3g iterations %.3g; waves finish at %.3f of the longest on average"
+                  % (deck, cap, n, r["kernel_ms"], r["kernel_ms"]*1e6/n, r["i_start"]/(r["kernel_ms"]*1e-3), st["passes"], st["iterations"], st["wave_life_sum"]/3072.0/max(1, st["wave_life_max"])), flush=True)
