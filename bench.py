@@ -347,12 +347,19 @@ def leak_workload(n_slots, dev_index):
     prob = polycap_amd.Problem(prof.get_z(), prof.get_cap(), prof.get_ext(), 0.0, 200000, 2.23, [10.0], a, s, *source)
     with polycap_amd.TraceContext(prob, dev_index) as c:
         c.transmission(1, 0, 4096, leak_calc=True)
+        c.transmission(20000, 0, n_slots, leak_calc=True, leak_views=True)       # sizes the context's buffers like a second call of a session
         t0 = time.perf_counter()
-        r = c.transmission(20000, 0, n_slots, leak_calc=True)
+        r = c.transmission(20000, 0, n_slots, leak_calc=True, leak_views=True)
         dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ext_copy, int_copy = c.leaks(copy=True)
+        dt_copy = time.perf_counter() - t0
         kernel = c.last_kernel()
     out = {"workload": "leak_calc=true, ellipsoidal test optic of the reference's tests/leaks.c, 10 keV, %d exit photons" % n_slots,
            "started_photons_per_s": r["i_start"] / (r["kernel_ms"] * 1e-3), "kernel_ms": r["kernel_ms"], "wall_ms": dt * 1e3,
+           "wall_what": "run + wait + totals + both event lists in host memory in the reference's list order (ordered on the device, one "
+                        "copy into the context's pinned lists, handed out as views)",
+           "wall_over_kernel": dt * 1e3 / r["kernel_ms"], "own_copies_of_the_lists_ms": dt_copy * 1e3,
            "n_started": r["i_start"], "n_exit": r["i_exit"], "extleak_events": len(r["ext"]), "intleak_events": len(r["int"]),
            "kernel": kernel, "valu_issue": pmc_block("profiles/r04/leak_pmc_summary.json", kernel, r["kernel_ms"])}
     try:

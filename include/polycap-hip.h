@@ -107,6 +107,8 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
  *   "log_cap"          reflections per log of the logging kernel (default 64, 1..255)
  *   "sweep_skip"       histogram-only runs of the logging kernel stop multiplying a weight once it is below 2^-64 (it adds
  *                      nothing to the exact sums any more; default 1)
+ *   "flush_max"        the logging kernel lets up to this many finished photons of a wave wait for a common sweep (default 8; the
+ *                      count is chosen so that the last pass of a sweep is nearly full: 3 at 291 energies)
  *   "sweep_fuse"       histogram-only runs of the logging kernel: the sweep of a photon that has left the optic adds its weights
  *                      to the sums itself, no weight row is written (default 1; 2: also for photons whose proxy energies are
  *                      dead, which exercises the exact take-back pass; 0: off)
@@ -180,6 +182,9 @@ POLYCAP_EXTERN int pc_hip_transmission_run_leak(pc_hip_ctx *ctx, uint64_t seed, 
 POLYCAP_EXTERN int pc_hip_leak_counts(pc_hip_ctx *ctx, int64_t *n_ext, int64_t *n_int);
 /* events [first, first+count) of kind 0 (extleak) or 1 (intleak) into records[count * (PC_HIP_LEAK_HDR + n_energies)] */
 POLYCAP_EXTERN int pc_hip_leak_events(pc_hip_ctx *ctx, int kind, int64_t first, int64_t count, double *records);
+/* the same without a copy: *records points at the context's own (pinned) list of *count events of that kind, in the reference's
+ * list order (put into it on the device); valid until the context's next leak run or its destruction */
+POLYCAP_EXTERN int pc_hip_leak_events_view(pc_hip_ctx *ctx, int kind, const double **records, int64_t *count);
 
 /* Waits until the context's device is idle (hipDeviceSynchronize): every stream, not only the context's own. */
 POLYCAP_EXTERN int pc_hip_device_synchronize(pc_hip_ctx *ctx);

@@ -128,6 +128,8 @@ def lib():
     L.pc_hip_leak_counts.restype = C.c_int
     L.pc_hip_leak_events.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, c_double_p]
     L.pc_hip_leak_events.restype = C.c_int
+    L.pc_hip_leak_events_view.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_double)), c_int64_p]
+    L.pc_hip_leak_events_view.restype = C.c_int
     L.pc_hip_sample_photons.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, c_int64_p, P(C.c_uint32), c_double_p]
     L.pc_hip_sample_photons.restype = C.c_int
     L.pc_hip_transmission_run.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_uint32, C.c_int]

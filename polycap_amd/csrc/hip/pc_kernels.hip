@@ -914,6 +914,7 @@ struct pc_hip_ctx {
 	                                * (pc_sweep_kernel.h), 0 = every reflection sweeps the weights at once */
 	int log_cap = 64;              /* option "log_cap": reflections per log of pc_trace_log_kernel */
 	int sweep_skip = 1;            /* option "sweep_skip": histogram-only log runs stop multiplying a weight below 2^-64 */
+	int flush_max = 8;             /* option "flush_max": at most this many finished photons of a wave wait for a common sweep */
 	int sweep_fuse = 1;            /* option "sweep_fuse": histogram-only log runs add a finished photon's weights to the sums in its sweep; 2 = also when
 	                                * its proxies are dead, so that photons the sweep finds dead exercise the take-back pass (tests) */
 	double *d_rlog = nullptr;
@@ -1014,7 +1015,12 @@ struct pc_hip_ctx {
 	long long leak_slot0 = 0, leak_n_slots = 0;
 	unsigned int leak_max_attempts = 0;
 	int leak_keep_images = 0;
-	std::vector<double> leak_ext, leak_int;   /* events of the last leak run, PC_HIP_LEAK_HDR + n_energies doubles each */
+	/* events of the last leak run in the reference's list order, PC_HIP_LEAK_HDR + n_energies doubles each: the extleak list, then
+	 * the intleak list, ordered on the device (pc_leak_collect) and kept in pinned host memory */
+	double *d_leak_out = nullptr, *h_leak_out = nullptr;
+	size_t leak_out_elems = 0;
+	void *d_leak_order_tmp = nullptr;
+	size_t leak_order_bytes = 0;
 	long long leak_n_ext = 0, leak_n_int = 0;
 };
 
@@ -1257,7 +1263,18 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 			a.rlog = ctx->d_rlog;
 			a.log_cap = ctx->log_cap;
 			a.stage_ps = (int)(stage/(PCS_ENT*(size_t)ctx->log_cap));
-			a.flush_min = std::max(1, std::min(a.stage_ps, (256 + ne - 1)/ne));
+			{
+				/* photons that wait for a sweep before one is run: the fewest (up to the stage's capacity) whose last pass leaves at
+				 * most 3 % of the round's lanes idle, else the count that leaves the fewest */
+				int best = 1;
+				double best_w = 2.;
+				for (int n = 1; n <= a.stage_ps && n <= ctx->flush_max; n++) {
+					const double w = (double)((64 - (n*ne) % 64) % 64) / (double)(n*ne);
+					if (w < best_w - 1e-12) { best_w = w; best = n; }
+					if (w <= 0.03) { best = n; break; }
+				}
+				a.flush_min = best;
+			}
 			a.n_proxy = ctx->sweep_n_proxy; a.proxy_e[0] = ctx->sweep_proxy_e[0]; a.proxy_e[1] = ctx->sweep_proxy_e[1];
 			a.ct_tame = ctx->sweep_ct_tame;
 			a.sweep_skip = (ctx->sweep_skip && !a.keep_images) ? 1 : 0;
@@ -1348,6 +1365,9 @@ void pc_hip_ctx_destroy(pc_hip_ctx *ctx)
 	if (ctx->h_batch) { if (ctx->h_batch_pinned) (void)hipHostFree(ctx->h_batch); else free(ctx->h_batch); }
 	if (ctx->d_leak_frames) (void)hipFree(ctx->d_leak_frames);
 	if (ctx->d_leak_records) (void)hipFree(ctx->d_leak_records);
+	if (ctx->d_leak_out) (void)hipFree(ctx->d_leak_out);
+	if (ctx->h_leak_out) (void)hipHostFree(ctx->h_leak_out);
+	if (ctx->d_leak_order_tmp) (void)hipFree(ctx->d_leak_order_tmp);
 	if (ctx->d_leak_cursor) (void)hipFree(ctx->d_leak_cursor);
 	if (ctx->d_amu) (void)hipFree(ctx->d_amu);
 	if (ctx->d_leak_attempts) (void)hipFree(ctx->d_leak_attempts);
@@ -1437,6 +1457,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "batch_reflections") ctx->batch_reflections = value ? 1 : 0;
 	else if (n == "log_cap") { if (value < 1 || value > 255) return pc_fail(PC_HIP_ERR_INVALID, "log_cap must be in [1,255]"); ctx->log_cap = (int)value; }
 	else if (n == "sweep_skip") ctx->sweep_skip = value ? 1 : 0;
+	else if (n == "flush_max") { if (value < 1 || value > 16) return pc_fail(PC_HIP_ERR_INVALID, "flush_max must be in [1,16]"); ctx->flush_max = (int)value; }
 	else if (n == "sweep_fuse") { if (value < 0 || value > 2) return pc_fail(PC_HIP_ERR_INVALID, "sweep_fuse must be 0, 1 or 2"); ctx->sweep_fuse = (int)value; }
 	else if (n == "plane_images") ctx->plane_images = value ? 1 : 0;
 	else if (n == "compact_images") ctx->compact_images = value ? 1 : 0;
@@ -1914,11 +1935,23 @@ int pc_hip_leak_events(pc_hip_ctx *ctx, int kind, int64_t first, int64_t count, 
 	if (kind != 0 && kind != 1) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_leak_events: kind must be 0 (extleak) or 1 (intleak)");
 	int st = pc_hip_transmission_wait(ctx, nullptr);
 	if (st) return st;
-	const std::vector<double> &src = kind == 0 ? ctx->leak_ext : ctx->leak_int;
 	const long long have = kind == 0 ? ctx->leak_n_ext : ctx->leak_n_int;
 	if (first < 0 || count < 0 || first + count > have) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_leak_events: range out of bounds");
 	const size_t stride = PC_HIP_LEAK_HDR + (size_t)ctx->host.pm.n_energies;
-	if (count) memcpy(records, src.data() + (size_t)first*stride, (size_t)count*stride*sizeof(double));
+	const double *src = ctx->h_leak_out + (kind == 0 ? 0 : (size_t)ctx->leak_n_ext*stride);
+	if (count) memcpy(records, src + (size_t)first*stride, (size_t)count*stride*sizeof(double));
+	return PC_HIP_OK;
+}
+
+int pc_hip_leak_events_view(pc_hip_ctx *ctx, int kind, const double **records, int64_t *count)
+{
+	if (!ctx || !records || !count) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_leak_events_view: NULL argument");
+	if (kind != 0 && kind != 1) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_leak_events_view: kind must be 0 (extleak) or 1 (intleak)");
+	int st = pc_hip_transmission_wait(ctx, nullptr);
+	if (st) return st;
+	const size_t stride = PC_HIP_LEAK_HDR + (size_t)ctx->host.pm.n_energies;
+	*count = kind == 0 ? ctx->leak_n_ext : ctx->leak_n_int;
+	*records = (*count > 0) ? ctx->h_leak_out + (kind == 0 ? 0 : (size_t)ctx->leak_n_ext*stride) : nullptr;
 	return PC_HIP_OK;
 }
 

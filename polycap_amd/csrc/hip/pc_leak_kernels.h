@@ -443,15 +443,111 @@ static int pc_leak_enqueue(pc_hip_ctx *ctx, pc_kargs &a, long long n_items, long
 	return PC_HIP_OK;
 }
 
-/* Brings the event records of the finished run to the host and turns them into the two lists of the reference
- * (src/polycap-source.c:799-879): attempts that appended a VOID record are dropped, the rest is ordered by slot, inside
- * a slot the transmitted attempt first and then the earlier attempts in attempt order, inside an attempt by seq.
- * Returns PC_HIP_OK, or 1 when the record buffer was too small (*needed = records the run produced). */
+/* ---------------------------------------------------------------------------------------------------------------------
+ * The events of a finished run, put into the two lists of the reference (src/polycap-source.c:799-879) ON THE DEVICE: attempts
+ * that appended a VOID record are dropped, the rest is ordered by slot, inside a slot the transmitted attempt first and then the
+ * earlier attempts in attempt order, inside an attempt by seq; extleak and intleak events go to lists of their own in that
+ * order.  Round 3 fetched the raw records (120 B each) and did this with host threads: 243 ms for the 2.46e6 events of the leak
+ * bench, more than the kernel.  Now: keys -> two stable radix sorts (seq, then (slot, order)) -> flags and positions (prefix sums)
+ * -> one gather into the output rows (PC_HIP_LEAK_HDR + n_energies doubles), which are copied once into pinned host memory. */
+#include <hipcub/hipcub.hpp>
+
+#define PC_LEAK_ORDER_BITS 22          /* order = 0 (the transmitted attempt) or attempt + 1 <= 2^20 + 1 */
+
+__global__ void __launch_bounds__(256) pc_leak_keys_kernel(const double *recs, long long stride, long long n, long long slot0, long long n_slots,
+	const unsigned int *final_attempt, unsigned long long *key, unsigned int *seq, unsigned int *idx,
+	unsigned long long *void_keys, unsigned int *void_n, unsigned int *bad)
+{
+	const long long k = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	const double *r = recs + k*stride;
+	const long long sl = (long long)r[PC_LR_SLOT] - slot0;
+	const long long att = (long long)r[PC_LR_ATTEMPT];
+	if (sl < 0 || sl >= n_slots || att < 0 || att + 1 >= (1ll << PC_LEAK_ORDER_BITS)) { atomicAdd(bad, 1u); key[k] = ~0ull; seq[k] = 0u; idx[k] = (unsigned int)k; return; }
+	/* the transmitted photon's own events come first (source runs; explicit photons have one attempt each) */
+	const long long order = (final_attempt != nullptr && (long long)final_attempt[sl] == att) ? 0 : att + 1;
+	const unsigned long long kk = ((unsigned long long)sl << PC_LEAK_ORDER_BITS) | (unsigned long long)order;
+	key[k] = kk;
+	seq[k] = (unsigned int)r[PC_LR_SEQ];
+	idx[k] = (unsigned int)k;
+	if (r[PC_LR_KIND] < 0.) void_keys[atomicAdd(void_n, 1u)] = kk;
+}
+
+__global__ void __launch_bounds__(256) pc_leak_gather_keys_kernel(const unsigned long long *key, const unsigned int *idx, long long n, unsigned long long *out)
+{
+	const long long k = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+	if (k < n) out[k] = key[idx[k]];
+}
+
+/* in sorted order: does the event go to the extleak / intleak list?  (not a VOID record, not of a voided attempt) */
+__global__ void __launch_bounds__(256) pc_leak_flags_kernel(const double *recs, long long stride, const unsigned long long *skey, const unsigned int *sidx,
+	long long n, const unsigned long long *void_sorted, const unsigned int *void_n, unsigned int *f_ext, unsigned int *f_int)
+{
+	const long long k = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+	if (k > n) return;
+	if (k == n) { f_ext[k] = 0u; f_int[k] = 0u; return; }     /* the prefix sums run over n + 1 flags: the last sums are the counts */
+	const double kind = recs[(long long)sidx[k]*stride + PC_LR_KIND];
+	const unsigned long long kk = skey[k];
+	bool keep = kind >= 0.;
+	if (keep) {
+		unsigned int lo = 0, hi = *void_n;
+		while (lo < hi) { const unsigned int mid = (lo + hi) >> 1; if (void_sorted[mid] < kk) lo = mid + 1; else hi = mid; }
+		if (lo < *void_n && void_sorted[lo] == kk) keep = false;
+	}
+	f_ext[k] = (keep && kind == (double)PC_LEAK_EXT) ? 1u : 0u;
+	f_int[k] = (keep && kind == (double)PC_LEAK_INT) ? 1u : 0u;
+}
+
+/* output rows: slot, attempt, coords, direction, electric vector, n_refl, weights; the intleak list behind the extleak list */
+__global__ void __launch_bounds__(256) pc_leak_rows_kernel(const double *recs, long long stride, const unsigned int *sidx, long long n, int ne,
+	const unsigned int *f_ext, const unsigned int *f_int, const unsigned int *p_ext, const unsigned int *p_int, double *out)
+{
+	const long long ostride = PC_HIP_LEAK_HDR + ne;
+	const long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+	const long long k = t / ostride;
+	const int c = (int)(t - k*ostride);
+	if (k >= n) return;
+	long long pos;
+	if (f_ext[k]) pos = (long long)p_ext[k];
+	else if (f_int[k]) pos = (long long)p_ext[n] + (long long)p_int[k];
+	else return;
+	const double *r = recs + (long long)sidx[k]*stride;
+	const int from = (c == 0) ? PC_LR_SLOT : ((c == 1) ? PC_LR_ATTEMPT : ((c < PC_HIP_LEAK_HDR) ? PC_LR_X + (c - 2) : PC_LR_WEIGHTS + (c - PC_HIP_LEAK_HDR)));
+	out[pos*ostride + c] = r[from];
+}
+
+static int pc_leak_order_buffers(pc_hip_ctx *ctx, size_t n, size_t ostride, size_t temp_bytes)
+{
+	/* keys n x 8 x 3, seq n x 4 x 2, idx n x 4 x 3, flags + positions (n + 1) x 4 x 4, void keys n x 8 x 2, counters */
+	const size_t need = n*8*3 + n*4*2 + n*4*3 + (n + 1)*4*4 + n*8*2 + 256 + temp_bytes + 4096;
+	if (need > ctx->leak_order_bytes) {
+		if (ctx->d_leak_order_tmp) (void)hipFree(ctx->d_leak_order_tmp);
+		ctx->d_leak_order_tmp = nullptr; ctx->leak_order_bytes = 0;
+		if (hipMalloc(&ctx->d_leak_order_tmp, need) != hipSuccess) { (void)hipGetLastError(); return pc_fail(PC_HIP_ERR_MEMORY, "leak run: could not allocate the ordering buffers"); }
+		ctx->leak_order_bytes = need;
+	}
+	const size_t out_elems = (n ? n : 1)*ostride;
+	if (out_elems > ctx->leak_out_elems) {
+		if (ctx->d_leak_out) (void)hipFree(ctx->d_leak_out);
+		if (ctx->h_leak_out) (void)hipHostFree(ctx->h_leak_out);
+		ctx->d_leak_out = nullptr; ctx->h_leak_out = nullptr; ctx->leak_out_elems = 0;
+		const size_t grow = out_elems + out_elems/8;
+		if (hipMalloc(&ctx->d_leak_out, grow*sizeof(double)) != hipSuccess || hipHostMalloc(&ctx->h_leak_out, grow*sizeof(double)) != hipSuccess) {
+			(void)hipGetLastError();
+			return pc_fail(PC_HIP_ERR_MEMORY, "leak run: could not allocate the event lists");
+		}
+		ctx->leak_out_elems = grow;
+	}
+	return PC_HIP_OK;
+}
+
+/* Orders the event records of the finished run on the device and brings the two lists to the host (pinned memory, kept by the
+ * context until its next leak run).  Returns PC_HIP_OK, or 1 when the record buffer was too small (*needed = records the run
+ * produced). */
 static int pc_leak_collect(pc_hip_ctx *ctx, long long n_slots, bool explicit_mode, long long *needed)
 {
 	unsigned long long cur[2] = {0, 0};
 	PC_HIP_CHECK(hipMemcpy(cur, ctx->d_leak_cursor, sizeof(cur), hipMemcpyDeviceToHost));
-	ctx->leak_ext.clear(); ctx->leak_int.clear();
 	if (ctx->d_leak_timing && getenv("POLYCAP_LEAK_TIMING")) {
 		const size_t nw = (size_t)ctx->leak_timing_waves;
 		std::vector<unsigned long long> t(nw*8);
@@ -478,85 +574,61 @@ static int pc_leak_collect(pc_hip_ctx *ctx, long long n_slots, bool explicit_mod
 	if (cur[1] != 0)
 		return pc_fail(PC_HIP_ERR_RUNTIME, "leak run: the chain of wall crossings was deeper than leak_max_depth for " + std::to_string(cur[1]) + " lane(s); raise the option leak_max_depth");
 	if ((long long)cur[0] > ctx->leak_capacity_used) { *needed = (long long)cur[0]; return 1; }
-	const size_t ne = (size_t)ctx->host.pm.n_energies, stride = PC_LR_HDR + ne, n = (size_t)cur[0];
-	std::vector<double> recs(n*stride);
-	if (n) PC_HIP_CHECK(hipMemcpy(recs.data(), ctx->d_leak_records, n*stride*sizeof(double), hipMemcpyDeviceToHost));
-	std::vector<unsigned int> final_attempt;
-	if (!explicit_mode) {
-		final_attempt.resize((size_t)n_slots);
-		PC_HIP_CHECK(hipMemcpy(final_attempt.data(), ctx->d_leak_attempts, (size_t)n_slots*sizeof(unsigned int), hipMemcpyDeviceToHost));
-	}
-	/* Ordering in O(n): records are bucketed by slot (counting sort), every bucket -- a few dozen events -- is put into
-	 * (transmitted attempt first, attempt, seq) order on its own, attempts that appended a VOID record are dropped; host
-	 * threads share the slot range and their pieces are concatenated in slot order.  (A comparison sort of all records
-	 * took 6 s for 7.6 M events.) */
-	const long long slot0 = ctx->leak_slot0;
-	const size_t ns = (size_t)n_slots;
-	std::vector<unsigned int> first(ns + 1, 0);
-	for (size_t k = 0; k < n; k++) {
-		const long long sl = (long long)recs[k*stride + PC_LR_SLOT] - slot0;
-		if (sl < 0 || sl >= n_slots) return pc_fail(PC_HIP_ERR_RUNTIME, "leak run: event record with a slot outside the run");
-		first[(size_t)sl + 1]++;
-	}
-	for (size_t j = 0; j < ns; j++) first[j + 1] += first[j];
-	std::vector<unsigned int> bucket(n), fill(first.begin(), first.end() - 1);
-	for (size_t k = 0; k < n; k++)
-		bucket[fill[(size_t)((long long)recs[k*stride + PC_LR_SLOT] - slot0)]++] = (unsigned int)k;
-	const size_t ostride = PC_HIP_LEAK_HDR + ne;
-	unsigned hw = std::thread::hardware_concurrency();
-	const size_t nthreads = (n < 200000) ? 1 : (hw == 0 ? 4 : (hw > 16 ? 16 : hw));
-	std::vector<std::vector<double>> out_ext(nthreads), out_int(nthreads);
-	auto work = [&](size_t t) {
-		const size_t j0 = ns*t/nthreads, j1 = ns*(t + 1)/nthreads;
-		struct item { long long order, seq; unsigned int idx; };
-		std::vector<item> items;
-		std::vector<long long> voided;
-		for (size_t j = j0; j < j1; j++) {
-			items.clear(); voided.clear();
-			for (unsigned int q = first[j]; q < first[j + 1]; q++) {
-				const double *r = recs.data() + (size_t)bucket[q]*stride;
-				if (r[PC_LR_KIND] < 0.) voided.push_back((long long)r[PC_LR_ATTEMPT]);
-			}
-			for (unsigned int q = first[j]; q < first[j + 1]; q++) {
-				const double *r = recs.data() + (size_t)bucket[q]*stride;
-				if (r[PC_LR_KIND] < 0.) continue;
-				const long long att = (long long)r[PC_LR_ATTEMPT];
-				if (!voided.empty() && std::find(voided.begin(), voided.end(), att) != voided.end()) continue;
-				long long order = att + 1;
-				if (!explicit_mode && (long long)final_attempt[j] == att) order = 0;   /* the transmitted photon's own events come first */
-				items.push_back({order, (long long)r[PC_LR_SEQ], bucket[q]});
-			}
-			std::sort(items.begin(), items.end(), [](const item &x, const item &y) {
-				if (x.order != y.order) return x.order < y.order;
-				return x.seq < y.seq; });
-			for (const item &it : items) {
-				const double *r = recs.data() + (size_t)it.idx*stride;
-				std::vector<double> &dst = (r[PC_LR_KIND] == (double)PC_LEAK_EXT) ? out_ext[t] : out_int[t];
-				const size_t at = dst.size();
-				dst.resize(at + ostride);
-				double *o = dst.data() + at;
-				o[0] = r[PC_LR_SLOT]; o[1] = r[PC_LR_ATTEMPT];
-				for (int c = 0; c < 10; c++) o[2 + c] = r[PC_LR_X + c];      /* coords, direction, elecv, n_refl */
-				for (size_t e = 0; e < ne; e++) o[PC_HIP_LEAK_HDR + e] = r[PC_LR_WEIGHTS + e];
-			}
-		}
-	};
-	{
-		std::vector<std::thread> th;
-		for (size_t t = 1; t < nthreads; t++) th.emplace_back(work, t);
-		work(0);
-		for (auto &x : th) x.join();
-	}
-	size_t tot_ext = 0, tot_int = 0;
-	for (size_t t = 0; t < nthreads; t++) { tot_ext += out_ext[t].size(); tot_int += out_int[t].size(); }
-	ctx->leak_ext.reserve(tot_ext); ctx->leak_int.reserve(tot_int);
-	for (size_t t = 0; t < nthreads; t++) {
-		ctx->leak_ext.insert(ctx->leak_ext.end(), out_ext[t].begin(), out_ext[t].end());
-		ctx->leak_int.insert(ctx->leak_int.end(), out_int[t].begin(), out_int[t].end());
-		std::vector<double>().swap(out_ext[t]); std::vector<double>().swap(out_int[t]);
-	}
-	ctx->leak_n_ext = (long long)(ctx->leak_ext.size() / ostride);
-	ctx->leak_n_int = (long long)(ctx->leak_int.size() / ostride);
+	const size_t ne = (size_t)ctx->host.pm.n_energies, stride = PC_LR_HDR + ne, ostride = PC_HIP_LEAK_HDR + ne, n = (size_t)cur[0];
+	if (n == 0) return PC_HIP_OK;
+	if (n >= (1ull << 32) - 2) return pc_fail(PC_HIP_ERR_INVALID, "leak run: more than 2^32 event records in one run; trace the slots in several runs");
+	hipStream_t st = ctx->stream;
+	const int end_bit = 64;
+	/* temporary storage of the library calls: the largest of the three sorts and the prefix sum */
+	size_t tb = 0, t1 = 0;
+	hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const unsigned int *)nullptr, (unsigned int *)nullptr, (const unsigned int *)nullptr, (unsigned int *)nullptr, (int)n, 0, 32, st); tb = std::max(tb, t1);
+	hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const unsigned int *)nullptr, (unsigned int *)nullptr, (int)n, 0, end_bit, st); tb = std::max(tb, t1);
+	hipcub::DeviceRadixSort::SortKeys(nullptr, t1, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (int)n, 0, end_bit, st); tb = std::max(tb, t1);
+	hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (const unsigned int *)nullptr, (unsigned int *)nullptr, (int)n + 1, st); tb = std::max(tb, t1);
+	int rc = pc_leak_order_buffers(ctx, n, ostride, tb);
+	if (rc) return rc;
+	char *base = (char *)ctx->d_leak_order_tmp;
+	auto take = [&](size_t bytes) { char *p = base; base += (bytes + 255) & ~(size_t)255; return (void *)p; };
+	unsigned long long *key = (unsigned long long *)take(n*8), *key2 = (unsigned long long *)take(n*8), *key3 = (unsigned long long *)take(n*8);
+	unsigned int *seq = (unsigned int *)take(n*4), *seq2 = (unsigned int *)take(n*4);
+	unsigned int *idx = (unsigned int *)take(n*4), *idx2 = (unsigned int *)take(n*4), *idx3 = (unsigned int *)take(n*4);
+	unsigned int *f_ext = (unsigned int *)take((n + 1)*4), *f_int = (unsigned int *)take((n + 1)*4), *p_ext = (unsigned int *)take((n + 1)*4), *p_int = (unsigned int *)take((n + 1)*4);
+	unsigned long long *vk = (unsigned long long *)take(n*8), *vk2 = (unsigned long long *)take(n*8);
+	unsigned int *cnt = (unsigned int *)take(64);       /* [0] void records, [1] records with a slot or attempt outside the run */
+	void *tmp = take(tb);
+	const unsigned blocks = (unsigned)((n + 255)/256);
+	PC_HIP_CHECK(hipMemsetAsync(cnt, 0, 64, st));
+	hipLaunchKernelGGL(pc_leak_keys_kernel, dim3(blocks), dim3(256), 0, st, ctx->d_leak_records, (long long)stride, (long long)n, (long long)ctx->leak_slot0, n_slots,
+	                   explicit_mode ? (const unsigned int *)nullptr : ctx->d_leak_attempts, key, seq, idx, vk, cnt, cnt + 1);
+	PC_HIP_CHECK(hipGetLastError());
+	unsigned int hc[2] = {0, 0};
+	PC_HIP_CHECK(hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+	PC_HIP_CHECK(hipStreamSynchronize(st));
+	if (hc[1]) return pc_fail(PC_HIP_ERR_RUNTIME, "leak run: event record with a slot or attempt outside the run");
+	if (hc[0]) PC_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(tmp, tb, vk, vk2, (int)hc[0], 0, end_bit, st));
+	/* stable sorts: by seq, then by (slot, order) */
+	PC_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tb, seq, seq2, idx, idx2, (int)n, 0, 32, st));
+	hipLaunchKernelGGL(pc_leak_gather_keys_kernel, dim3(blocks), dim3(256), 0, st, key, idx2, (long long)n, key2);
+	PC_HIP_CHECK(hipGetLastError());
+	PC_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key2, key3, idx2, idx3, (int)n, 0, end_bit, st));
+	hipLaunchKernelGGL(pc_leak_flags_kernel, dim3((unsigned)((n + 1 + 255)/256)), dim3(256), 0, st, ctx->d_leak_records, (long long)stride, key3, idx3, (long long)n,
+	                   hc[0] ? vk2 : vk, cnt, f_ext, f_int);
+	PC_HIP_CHECK(hipGetLastError());
+	PC_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, f_ext, p_ext, (int)n + 1, st));
+	PC_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, f_int, p_int, (int)n + 1, st));
+	const unsigned long long cells = (unsigned long long)n*ostride;
+	hipLaunchKernelGGL(pc_leak_rows_kernel, dim3((unsigned)((cells + 255)/256)), dim3(256), 0, st, ctx->d_leak_records, (long long)stride, idx3, (long long)n, (int)ne,
+	                   f_ext, f_int, p_ext, p_int, ctx->d_leak_out);
+	PC_HIP_CHECK(hipGetLastError());
+	unsigned int tot[2] = {0, 0};
+	PC_HIP_CHECK(hipMemcpyAsync(&tot[0], p_ext + n, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+	PC_HIP_CHECK(hipMemcpyAsync(&tot[1], p_int + n, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+	PC_HIP_CHECK(hipStreamSynchronize(st));
+	const size_t rows = (size_t)tot[0] + (size_t)tot[1];
+	if (rows) PC_HIP_CHECK(hipMemcpyAsync(ctx->h_leak_out, ctx->d_leak_out, rows*ostride*sizeof(double), hipMemcpyDeviceToHost, st));
+	PC_HIP_CHECK(hipStreamSynchronize(st));
+	ctx->leak_n_ext = (long long)tot[0];
+	ctx->leak_n_int = (long long)tot[1];
 	return PC_HIP_OK;
 }
 

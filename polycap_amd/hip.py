@@ -111,21 +111,26 @@ class TraceContext:
             raise HipError("pc_hip_transmission_run_leak" if leak_calc else "pc_hip_transmission_run", st)
         self._last_n = int(n_slots)
 
-    def leaks(self):
+    def leaks(self, copy=True):
         """(ext, int): the leak events of the last leak_calc run, arrays [n, 12 + nE] with columns slot, attempt,
-        x, y, z, dir x y z, elecv x y z, n_refl, weights; in the reference's list order."""
-        ne_, ni_ = C.c_int64(0), C.c_int64(0)
-        st = self._L.pc_hip_leak_counts(self._h, C.byref(ne_), C.byref(ni_))
-        if st != _cabi.PC_HIP_OK:
-            raise HipError("pc_hip_leak_counts", st)
+        x, y, z, dir x y z, elecv x y z, n_refl, weights; in the reference's list order (the device puts them into it).
+        copy=False: read-only views of the context's own pinned lists, valid until its next leak run."""
         out = []
         stride = _cabi.PC_HIP_LEAK_HDR + self.problem.n_energies
-        for kind, n in ((0, ne_.value), (1, ni_.value)):
-            a = np.zeros((n, stride))
-            if n:
-                st = self._L.pc_hip_leak_events(self._h, kind, 0, n, dptr(a))
-                if st != _cabi.PC_HIP_OK:
-                    raise HipError("pc_hip_leak_events", st)
+        for kind in (0, 1):
+            ptr = C.POINTER(C.c_double)()
+            n = C.c_int64(0)
+            st = self._L.pc_hip_leak_events_view(self._h, kind, C.byref(ptr), C.byref(n))
+            if st != _cabi.PC_HIP_OK:
+                raise HipError("pc_hip_leak_events_view", st)
+            if n.value == 0:
+                out.append(np.zeros((0, stride)))
+                continue
+            a = np.ctypeslib.as_array(ptr, shape=(n.value, stride))
+            if copy:
+                a = a.copy()
+            else:
+                a.flags.writeable = False
             out.append(a)
         return out[0], out[1]
 
@@ -234,8 +239,8 @@ class TraceContext:
             raise HipError("pc_hip_leak_slot_units", st)
         return u
 
-    def transmission(self, seed, slot0, n_slots, max_attempts=1 << 20, keep_images=False, leak_calc=False):
-        """run + wait + totals (+ images, + leak events) in one call."""
+    def transmission(self, seed, slot0, n_slots, max_attempts=1 << 20, keep_images=False, leak_calc=False, leak_views=False):
+        """run + wait + totals (+ images, + leak events: copies, or with leak_views views of the context's lists) in one call."""
         self.run(seed, slot0, n_slots, max_attempts, keep_images, leak_calc)
         ms = self.wait()
         r = self.totals()
@@ -244,7 +249,7 @@ class TraceContext:
         if keep_images:
             r.update(self.images(0, n_slots))
         if leak_calc:
-            r["ext"], r["int"] = self.leaks()
+            r["ext"], r["int"] = self.leaks(copy=not leak_views)
         return r
 
 
