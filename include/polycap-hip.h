@@ -202,6 +202,12 @@ POLYCAP_EXTERN void pc_hip_group_destroy(pc_hip_group *group);
 POLYCAP_EXTERN int pc_hip_group_size(const pc_hip_group *group);
 POLYCAP_EXTERN int pc_hip_group_set_option(pc_hip_group *group, const char *name, int64_t value);
 POLYCAP_EXTERN int pc_hip_group_run(pc_hip_group *group, uint64_t seed, int64_t n_slots, uint32_t max_attempts, int keep_images);
+/* leak_calc = true over the group: every member traces its contiguous slot range and orders its events on its own device; the
+ * group's event lists are the members' lists one after the other (= slot order, as one device produces them).  Images and
+ * totals through pc_hip_group_images / pc_hip_group_totals. */
+POLYCAP_EXTERN int pc_hip_group_run_leak(pc_hip_group *group, uint64_t seed, int64_t n_slots, uint32_t max_attempts, int keep_images);
+POLYCAP_EXTERN int pc_hip_group_leak_counts(pc_hip_group *group, int64_t *n_ext, int64_t *n_int);
+POLYCAP_EXTERN int pc_hip_group_leak_events(pc_hip_group *group, int kind, int64_t first, int64_t count, double *records);
 /* kernel that traced member k's share of the last run (as pc_hip_last_kernel) */
 POLYCAP_EXTERN int pc_hip_group_last_kernel(pc_hip_group *group, int k);
 /* image planes of all n_slots slots of the last run (one host thread per member copies its range into dst) */
@@ -226,6 +232,9 @@ POLYCAP_EXTERN int pc_hip_last_kernel(pc_hip_ctx *ctx);
  * every energy's reflectivity inside [0, 1 - 1e-11] (-1: no log run yet); proxies (optional) = the one or two energy indices
  * every lane follows itself (-1: none) */
 POLYCAP_EXTERN int pc_hip_sweep_stats(pc_hip_ctx *ctx, int64_t stats[4], double *ct_tame, int proxies[2]);
+
+/* 1 when the host address lies in memory registered with (pinned by) the HIP runtime */
+POLYCAP_EXTERN int pc_hip_host_is_pinned(const void *p);
 
 /* efficiency formula of src/polycap-source.c:1066-1076 from (summed) totals */
 POLYCAP_EXTERN void pc_hip_efficiencies(size_t n_energies, const double *sum_weights, const int64_t counters[6], double *efficiencies);

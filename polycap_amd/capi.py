@@ -141,7 +141,7 @@ def _lib():
     return L
 
 
-_EXC = {0: MemoryError, 1: ValueError, 2: IOError, 3: RuntimeError, 4: TypeError, 5: NotImplementedError, 6: RuntimeError}
+_EXC = {0: MemoryError, 1: ValueError, 2: IOError, 3: IOError, 4: TypeError, 5: NotImplementedError, 6: RuntimeError}
 
 
 def _check(err):

@@ -59,6 +59,7 @@ struct pc_hip_group {
 	size_t vec_len = 0;
 	long long run_slots = 0;
 	int keep_images = 0;
+	int leak_run = 0;                           /* the last run was a leak run (pc_hip_group_run_leak) */
 };
 
 /* totals of one device -> the vector that is all-reduced: counters, then the (lo, hi) sums as 32-bit limbs */
@@ -136,10 +137,11 @@ int pc_hip_group_set_option(pc_hip_group *g, const char *name, int64_t value)
 	return PC_HIP_OK;
 }
 
-int pc_hip_group_run(pc_hip_group *g, uint64_t seed, int64_t n_slots, uint32_t max_attempts, int keep_images)
+static int pc_group_run_impl(pc_hip_group *g, uint64_t seed, int64_t n_slots, uint32_t max_attempts, int keep_images, bool leak)
 {
 	if (!g) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_group_run: group must not be NULL");
 	if (n_slots < 1) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_group_run: n_slots must be >= 1");
+	g->leak_run = leak ? 1 : 0;
 	const size_t N = g->ctx.size();
 	g->run_slots = n_slots;
 	g->keep_images = keep_images ? 1 : 0;
@@ -148,7 +150,7 @@ int pc_hip_group_run(pc_hip_group *g, uint64_t seed, int64_t n_slots, uint32_t m
 	 * context probes by itself (1e7 slots over 8 devices), and eight probes one after the other would serialise the enqueue. */
 	{
 		pc_hip_ctx *c0 = g->ctx[0];
-		if (c0->producer < 0 && c0->refl_per_launch < 0. && c0->host.pm.n_energies == 1 && n_slots >= 2000000) {
+		if (!leak && c0->producer < 0 && c0->refl_per_launch < 0. && c0->host.pm.n_energies == 1 && n_slots >= 2000000) {
 			if (max_attempts < 1) max_attempts = 1;
 			int st = pc_probe_lifetime(c0, seed, 0, max_attempts);
 			if (st) return st;
@@ -166,7 +168,8 @@ int pc_hip_group_run(pc_hip_group *g, uint64_t seed, int64_t n_slots, uint32_t m
 	std::vector<std::string> msg(N);
 	auto enqueue = [&](size_t k) {
 		if (g->count[k] == 0) return;
-		status[k] = pc_hip_transmission_run(g->ctx[k], seed, g->first[k], g->count[k], max_attempts, keep_images);
+		status[k] = leak ? pc_hip_transmission_run_leak(g->ctx[k], seed, g->first[k], g->count[k], max_attempts, keep_images)
+		                 : pc_hip_transmission_run(g->ctx[k], seed, g->first[k], g->count[k], max_attempts, keep_images);
 		if (status[k]) msg[k] = g_last_error;       /* the error text is per thread */
 	};
 	{
@@ -182,6 +185,62 @@ int pc_hip_group_run(pc_hip_group *g, uint64_t seed, int64_t n_slots, uint32_t m
 			if (g->ctx[j]->run_pending) (void)pc_hip_transmission_wait(g->ctx[j], nullptr);
 		return pc_fail(status[k], msg[k]);
 	}
+	return PC_HIP_OK;
+}
+
+int pc_hip_group_run(pc_hip_group *g, uint64_t seed, int64_t n_slots, uint32_t max_attempts, int keep_images)
+{
+	return pc_group_run_impl(g, seed, n_slots, max_attempts, keep_images, false);
+}
+
+/* leak_calc = true over the group (reference: the whole OpenMP team traces leak runs too, src/polycap-source.c:744-884, and the
+ * threads' event lists are appended one after the other, :925-1032): every member traces its contiguous slot range with its
+ * events ordered on its own device; the group's lists are the members' lists in member order, i.e. in slot order. */
+int pc_hip_group_run_leak(pc_hip_group *g, uint64_t seed, int64_t n_slots, uint32_t max_attempts, int keep_images)
+{
+	return pc_group_run_impl(g, seed, n_slots, max_attempts, keep_images, true);
+}
+
+int pc_hip_group_leak_counts(pc_hip_group *g, int64_t *n_ext, int64_t *n_int)
+{
+	if (!g) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_group_leak_counts: group must not be NULL");
+	if (!g->leak_run) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_group_leak_counts: the last run of the group was not a leak run");
+	int64_t e = 0, i = 0;
+	for (size_t k = 0; k < g->ctx.size(); k++) {
+		if (g->count[k] == 0) continue;
+		int64_t a = 0, b = 0;
+		int st = pc_hip_leak_counts(g->ctx[k], &a, &b);
+		if (st) return st;
+		e += a; i += b;
+	}
+	if (n_ext) *n_ext = e;
+	if (n_int) *n_int = i;
+	return PC_HIP_OK;
+}
+
+int pc_hip_group_leak_events(pc_hip_group *g, int kind, int64_t first, int64_t count, double *records)
+{
+	if (!g || (count > 0 && !records)) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_group_leak_events: NULL argument");
+	if (!g->leak_run) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_group_leak_events: the last run of the group was not a leak run");
+	if (kind != 0 && kind != 1) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_group_leak_events: kind must be 0 (extleak) or 1 (intleak)");
+	if (first < 0 || count < 0) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_group_leak_events: range out of bounds");
+	const size_t stride = PC_HIP_LEAK_HDR + (size_t)g->ctx[0]->host.pm.n_energies;
+	int64_t base = 0, left = count, at = first;
+	for (size_t k = 0; k < g->ctx.size() && left > 0; k++) {
+		if (g->count[k] == 0) continue;
+		int64_t n[2] = {0, 0};
+		int st = pc_hip_leak_counts(g->ctx[k], &n[0], &n[1]);
+		if (st) return st;
+		const int64_t have = n[kind];
+		if (at < base + have) {
+			const int64_t lo = at - base, take = (have - lo < left) ? have - lo : left;
+			st = pc_hip_leak_events(g->ctx[k], kind, lo, take, records);
+			if (st) return st;
+			records += (size_t)take*stride; at += take; left -= take;
+		}
+		base += have;
+	}
+	if (left > 0) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_group_leak_events: range out of bounds");
 	return PC_HIP_OK;
 }
 

@@ -600,10 +600,17 @@ pc_trace_kernel(pc_kargs a)
 									pc_atomic_add128(a.sumw + 2*e, f, 0ull);
 								}
 							}
-							if (a.keep_images) a.img_w[slot_p*ws + e] = w;
+							if (a.keep_images) { if (compact) pc_store_wt(a.img_w + slot_p*ws + e, w); else a.img_w[slot_p*ws + e] = w; }
 						}
 					}
 				}
+			}
+			/* compact store: the positions [c_base, c_base + c_k) are complete (fields above, weights by the lanes or the cooperative
+			 * sweep): count them into their blocks once the stores have reached memory, so that the fetch can copy a finished block
+			 * while the kernel runs (the launching-wave kernel does the same, pc_producer_kernel.h) */
+			if (compact && c_k > 0 && a.blk_done) {
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				if (lane == 0) pc_blocks_written(a, c_base, c_k);
 			}
 			/* hand out slots: wave-uniform chunk, refilled from the global counter by one lane */
 			{
@@ -723,6 +730,22 @@ pc_trace_kernel(pc_kargs a)
 #include "pc_wave_kernel.h"      /* the one-wave-per-photon experiment (profiles/r03/wave_per_photon_ab.txt): not part of the product build */
 #endif
 #include "pc_sweep_kernel.h"
+
+/* Compact store: slots that used up their attempts without a transmitted photon wrote nothing (the slot-ordered store writes
+ * zero weights for them), so the positions behind the run's cursor hold whatever the buffer held: zero them once the trace
+ * kernel has ended -- every plane and the weights -- so that a result with failed slots never carries stale data. */
+__global__ void __launch_bounds__(256) pc_compact_tail_kernel(double *soa, long long n_total, int ne, const unsigned long long *cursor)
+{
+	const long long c = (long long)*cursor;
+	if (c >= n_total) return;
+	const long long cells = (n_total - c)*(long long)(PC_N_FIELDS + ne);
+	for (long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x; t < cells; t += (long long)gridDim.x*blockDim.x) {
+		const long long p = c + t / (PC_N_FIELDS + ne);
+		const int f = (int)(t % (PC_N_FIELDS + ne));
+		if (f < PC_N_FIELDS) soa[(long long)f*n_total + p] = 0.;
+		else soa[(long long)PC_N_FIELDS*n_total + p*ne + (f - PC_N_FIELDS)] = 0.;
+	}
+}
 
 /* Image records (one contiguous record of 17 + n_energies doubles per slot) -> the planes of struct _polycap_images: 17
  * planes of n_total doubles each, then the weights as [slot][n_energies].  A workgroup stages PC_SOA_TILE records in LDS
@@ -1709,6 +1732,12 @@ static int pc_probe_lifetime(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, uint
  * flags, the lanes' start-image lines and, on request, the plane of slot indices; counters and flags are cleared */
 static int pc_compact_prepare(pc_hip_ctx *ctx, long long n_slots)
 {
+	/* the block flags are cleared from the host below: a run of this context that is still in flight would set flags of its own
+	 * after that (and the fetch of the new run would copy blocks the new kernel has not written) */
+	if (ctx->run_pending) {
+		int st = pc_hip_transmission_wait(ctx, nullptr);
+		if (st) return st;
+	}
 	const int shift = ctx->blk_shift;
 	const size_t blocks = (size_t)((n_slots + (1ll << shift) - 1) >> shift);
 	if (!ctx->d_cursor) PC_HIP_CHECK(hipMalloc(&ctx->d_cursor, sizeof(unsigned long long)));
@@ -1743,7 +1772,7 @@ static int pc_compact_prepare(pc_hip_ctx *ctx, long long n_slots)
 	}
 	ctx->run_blk_shift = shift;
 	ctx->run_blocks = (long long)blocks;
-	memset(ctx->h_blk_flag, 0, blocks*sizeof(unsigned int));      /* the previous run has been waited for: nobody looks at them now */
+	memset(ctx->h_blk_flag, 0, blocks*sizeof(unsigned int));      /* the previous run has been waited for (above): nobody looks at them now */
 	PC_HIP_CHECK(hipMemsetAsync(ctx->d_cursor, 0, sizeof(unsigned long long), ctx->stream));
 	PC_HIP_CHECK(hipMemsetAsync(ctx->d_blk_done, 0, blocks*sizeof(unsigned int), ctx->stream));
 	return PC_HIP_OK;
@@ -1830,8 +1859,14 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 			a.work = ctx->d_work + k;
 			ctx->stream = (k & 1) ? ctx->stream2 : main_stream;
 		}
+		if (compact) ctx->rec_ev1 = false;       /* the kernel time ends behind the tail kernel below */
 		status = ctx->host.pm.generic_src ? pc_launch_kernel<PC_MODE_SRC_GENERIC>(ctx, a, hi - lo)
 		                                  : pc_launch_kernel<PC_MODE_SRC_CIRCULAR>(ctx, a, hi - lo);
+		if (compact && status == PC_HIP_OK) {
+			hipLaunchKernelGGL(pc_compact_tail_kernel, dim3(64), dim3(256), 0, ctx->stream, ctx->d_soa, (long long)n_slots, (int)ne, ctx->d_cursor);
+			PC_HIP_CHECK(hipGetLastError());
+			PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+		}
 		ctx->part_end[k] = hi;
 		if (status == PC_HIP_OK && parts > 1) {
 			if (!ctx->ev_part[k]) PC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_part[k], hipEventDisableTiming));
@@ -1917,6 +1952,16 @@ int pc_hip_transmission_wait(pc_hip_ctx *ctx, float *kernel_ms)
 	}
 	if (kernel_ms) *kernel_ms = ctx->last_ms;
 	return PC_HIP_OK;
+}
+
+/* is this host address registered with the HIP runtime (pinned)? */
+int pc_hip_host_is_pinned(const void *p)
+{
+	if (p == nullptr) return 0;
+	unsigned int flags = 0;
+	if (hipHostGetFlags(&flags, const_cast<void *>(p)) == hipSuccess) return 1;
+	(void)hipGetLastError();
+	return 0;
 }
 
 int pc_hip_leak_counts(pc_hip_ctx *ctx, int64_t *n_ext, int64_t *n_int)

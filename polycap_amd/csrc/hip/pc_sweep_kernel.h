@@ -489,9 +489,14 @@ pc_trace_log_kernel(pc_kargs a)
 								if (old + f < old) atomicAdd(&l_acc[2*e + 1], 1ull);
 							}
 						}
-						if (a.keep_images) a.img_w[slot_p*ws + e] = w;
+						if (a.keep_images) { if (compact) pc_store_wt(a.img_w + slot_p*ws + e, w); else a.img_w[slot_p*ws + e] = w; }
 					}
 				}
+			}
+			/* compact store: the positions taken above are complete: count them into their blocks (pc_trace_kernel does the same) */
+			if (compact && c_k > 0 && a.blk_done) {
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				if (lane == 0) pc_blocks_written(a, c_base, c_k);
 			}
 			/* hand out slots: wave-uniform chunk, refilled from the global counter by one lane.  Near the end of the launch a
 			 * request is served with its share of what is left (header comment, "slots") */

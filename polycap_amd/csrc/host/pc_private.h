@@ -161,7 +161,7 @@ POLYCAP_EXTERN int pc_transmission_efficiencies_slab(const polycap_transmission_
 void pc_transeff_prefault(polycap_transmission_efficiencies *eff, size_t np);
 void pc_transeff_plane_pointers(polycap_transmission_efficiencies *eff, pc_hip_images *dst);
 void pc_transeff_finish(polycap_transmission_efficiencies *eff, const double *sum_weights, const int64_t counters[6]);
-int pc_transeff_fetch_leaks(polycap_transmission_efficiencies *eff, pc_hip_ctx *ctx);   /* returns a pc_hip_status */
+int pc_transeff_fetch_leaks(polycap_transmission_efficiencies *eff, pc_hip_ctx *ctx, pc_hip_group *group);   /* one of ctx / group; returns a pc_hip_status */
 
 /* leak events of the last leak_calc run of `ctx` as polycap_leak lists (pc_photon.c); *list is malloc'd, NULL when empty */
 int pc_fetch_leaks(pc_hip_ctx *ctx, int kind, size_t n_energies, polycap_leak ***list, int64_t *n, int64_t **slots,

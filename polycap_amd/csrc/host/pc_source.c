@@ -410,8 +410,6 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 		polycap_set_error_literal(error, POLYCAP_ERROR_INVALID_ARGUMENT, "polycap_source_get_transmission_efficiencies: POLYCAP_IMAGES=0 cannot be combined with leak_calc (leak events are per-photon data)");
 		return NULL;
 	}
-	if (leak_calc && n_devices > 1)
-		n_devices = 1;      /* leak runs keep their event lists on one device: the first of the list */
 	double t_stage[8];
 	t_stage[0] = pc_now_ms();
 	polycap_transmission_efficiencies *eff = pc_transeff_alloc(source, keep_images ? (size_t)n_photons : 0, 0, "polycap_source_get_transmission_efficiencies", error);
@@ -426,9 +424,9 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 
 	pc_hip_ctx *ctx = NULL;
 	pc_hip_group *group = NULL;
-	if (n_devices > 0 && !leak_calc)
+	if (n_devices > 1 || (n_devices > 0 && !leak_calc))      /* leak runs are sharded like plain runs (reference :744-884, 925-1032) */
 		group = pc_group_for(&source->cache, description, ne, source->energies, source, n_devices, devices, "polycap_source_get_transmission_efficiencies", error);
-	else      /* a one-entry list (or the first entry, for a leak run) selects the device; none: POLYCAP_HIP_DEVICE, default 0 */
+	else      /* a one-entry list selects the device of a leak run; none: POLYCAP_HIP_DEVICE, default 0 */
 		ctx = pc_ctx_for_device(&source->cache, description, ne, source->energies, source, n_devices >= 1 ? devices[0] : -1,
 		                        "polycap_source_get_transmission_efficiencies", error);
 	if (ctx == NULL && group == NULL) {
@@ -458,9 +456,10 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 		if (status == PC_HIP_OK)
 			status = pc_hip_group_set_option(group, "compact_images", compact);
 		if (status == PC_HIP_OK)
-			status = pc_hip_group_set_option(group, "plane_images", 1);
+			status = pc_hip_group_set_option(group, "plane_images", leak_calc ? 0 : 1);
 		if (status == PC_HIP_OK)
-			status = pc_hip_group_run(group, seed, n_photons, max_attempts, keep_images);
+			status = leak_calc ? pc_hip_group_run_leak(group, seed, n_photons, max_attempts, 1)
+			                   : pc_hip_group_run(group, seed, n_photons, max_attempts, keep_images);
 	} else {
 		status = pc_hip_set_option(ctx, "run_parts", parts);
 		if (status == PC_HIP_OK)
@@ -510,7 +509,7 @@ polycap_transmission_efficiencies *polycap_source_get_transmission_efficiencies(
 			t_stage[1] - t_stage[0], t_stage[2] - t_stage[1], t_stage[3] - t_stage[2], t_stage[4] - t_stage[3], t_stage[5] - t_stage[4],
 			group != NULL ? (reduced_by ? " (devices summed by RCCL all-reduce)" : " (devices summed on the host)") : "");
 	if (status == PC_HIP_OK && leak_calc)
-		status = pc_transeff_fetch_leaks(eff, ctx);      /* reference :925-1032 */
+		status = pc_transeff_fetch_leaks(eff, ctx, group);      /* reference :925-1032 */
 	if (status != PC_HIP_OK) {
 		pc_set_hip_error(error, "polycap_source_get_transmission_efficiencies", status);
 		free(sum_weights);

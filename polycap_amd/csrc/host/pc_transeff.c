@@ -345,13 +345,15 @@ void pc_transeff_prefault(polycap_transmission_efficiencies *eff, size_t np)
 		if (started & (1 << t)) pthread_join(th[t], NULL);
 }
 
-/* the image fetch has pinned the (large) planes and left them pinned (option "keep_pinned"): remember it in their headers */
+/* the image fetch may have pinned the (large) planes and left them pinned (option "keep_pinned"): remember in their header what
+ * the runtime says about them now -- a fetch that fell back to pinning plane by plane, or whose registration was refused, leaves
+ * the slab unpinned, and the pool and the free path must not treat it as registered */
 void pc_transeff_planes_pinned(polycap_transmission_efficiencies *eff)
 {
 	if (eff == NULL || eff->images == NULL)
 		return;
 	if (eff->images->slab != NULL)
-		pc_plane_set_pinned(eff->images->slab, 1);
+		pc_plane_set_pinned(eff->images->slab, pc_hip_host_is_pinned(eff->images->slab));
 }
 
 /* totals -> open area, counts and efficiencies (reference: src/polycap-source.c:1061-1076) */
@@ -539,12 +541,12 @@ bool polycap_transmission_efficiencies_get_exit_data(polycap_transmission_effici
 
 /* Leak events of the finished leak_calc run of `ctx` -> the leak planes of eff->images (reference: src/polycap-source.c:
  * 982-1032).  Fetched in blocks of records (include/polycap-hip.h) and scattered into the planes. */
-int pc_transeff_fetch_leaks(polycap_transmission_efficiencies *eff, pc_hip_ctx *ctx)
+int pc_transeff_fetch_leaks(polycap_transmission_efficiencies *eff, pc_hip_ctx *ctx, pc_hip_group *group)
 {
 	struct _polycap_images *im = eff->images;
 	const size_t ne = eff->n_energies, stride = PC_HIP_LEAK_HDR + ne;
 	int64_t n_kind[2] = {0, 0};
-	int status = pc_hip_leak_counts(ctx, &n_kind[0], &n_kind[1]);
+	int status = (group != NULL) ? pc_hip_group_leak_counts(group, &n_kind[0], &n_kind[1]) : pc_hip_leak_counts(ctx, &n_kind[0], &n_kind[1]);
 	if (status != PC_HIP_OK)
 		return status;
 	const int64_t block = 65536;
@@ -576,7 +578,7 @@ int pc_transeff_fetch_leaks(polycap_transmission_efficiencies *eff, pc_hip_ctx *
 		if (!ok) { status = PC_HIP_ERR_MEMORY; break; }
 		for (int64_t first = 0; first < (int64_t)n && status == PC_HIP_OK; first += block) {
 			const int64_t count = ((int64_t)n - first < block) ? (int64_t)n - first : block;
-			status = pc_hip_leak_events(ctx, kind, first, count, rec);
+			status = (group != NULL) ? pc_hip_group_leak_events(group, kind, first, count, rec) : pc_hip_leak_events(ctx, kind, first, count, rec);
 			if (status != PC_HIP_OK)
 				break;
 			for (int64_t k = 0; k < count; k++) {

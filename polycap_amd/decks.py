@@ -10,7 +10,7 @@ from ._cabi import ErrS as _ErrS
 
 
 # polycap_error codes -> Python exceptions as in the reference's binding (python/polycap.pyx:91-107)
-_EXC = {0: MemoryError, 1: ValueError, 2: IOError, 3: RuntimeError, 4: TypeError, 5: NotImplementedError, 6: RuntimeError}
+_EXC = {0: MemoryError, 1: ValueError, 2: IOError, 3: IOError, 4: TypeError, 5: NotImplementedError, 6: RuntimeError}
 
 
 def _raise(L, err, where):
