@@ -166,12 +166,7 @@ def main():
         wall = float(tt.item())
         # one extra gather, outside the timed region: every rank's mean kernel time, so that the scaling record shows that the
         # collective saw all the ranks and where the tail of a step is
-        mine = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=red_dev if red_dev is not None else "cpu")
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        per_rank = [float(x.item()) for x in every]
-        rccl = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                "per_rank_kernel_ms": [min(per_rank), max(per_rank)], "ranks_seen": len(per_rank)}
+        rccl = pcd.ranks_report(float(np.mean(kernel_ms)), red_dev)
 
     if rank == 0:
         counters, sums = last

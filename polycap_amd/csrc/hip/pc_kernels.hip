@@ -978,6 +978,8 @@ struct pc_hip_ctx {
 	/* option "compact_images" (with plane_images): exit photons are stored in the order of completion, one coalesced run per
 	 * plane and batch, and the planes are published block by block while the kernel runs (pc_kargs::img_cursor) */
 	int compact_images = 0;
+	int compact_parts = 1;                 /* option "compact_parts": launches a compact run of 4e6 slots or more is traced in (alternating between two
+	                                        * streams).  Measured, not adopted: 2 launches 20.95 ms against 19.6 ms for one (1e7 slots; profiles/r04/kernel_history.md) */
 	int run_compact = 0;                   /* the last run did so */
 	int dst_prepinned = 0;                 /* the caller (a device group) has pinned the destination planes itself: the fetch pins nothing */
 	int keep_pinned = 0;                   /* option "keep_pinned": pc_hip_transmission_images leaves the destination planes pinned */
@@ -1484,6 +1486,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "sweep_fuse") { if (value < 0 || value > 2) return pc_fail(PC_HIP_ERR_INVALID, "sweep_fuse must be 0, 1 or 2"); ctx->sweep_fuse = (int)value; }
 	else if (n == "plane_images") ctx->plane_images = value ? 1 : 0;
 	else if (n == "compact_images") ctx->compact_images = value ? 1 : 0;
+	else if (n == "compact_parts") { if (value < 1 || value > PC_MAX_PARTS) return pc_fail(PC_HIP_ERR_INVALID, "compact_parts must be in [1,16]"); ctx->compact_parts = (int)value; }
 	else if (n == "slot_ids") ctx->slot_ids = value ? 1 : 0;
 	else if (n == "keep_pinned") ctx->keep_pinned = value ? 1 : 0;
 	else if (n == "block_shift") { if (value < 7 || value > 30) return pc_fail(PC_HIP_ERR_INVALID, "block_shift must be in [7,30]"); ctx->blk_shift = (int)value; }
@@ -1826,11 +1829,16 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 	a.seed = seed; a.max_attempts = max_attempts; a.keep_images = keep_images ? 1 : 0;
 	/* parts: consecutive slot ranges traced by consecutive launches into the same totals and image records (a photon
 	 * depends on its global slot number only, so the result does not depend on the cut) */
-	int parts = (keep_images && ctx->run_parts > 1 && !compact) ? ctx->run_parts : 1;      /* a compact run publishes its blocks itself */
+	/* A compact run publishes its blocks itself: it needs no parts for the copy-back.  Option "compact_parts" > 1 traces a big one
+	 * as that many launches on two streams all the same (the positions, block counters and totals are the run's, so a launch simply
+	 * goes on where the one before leaves off): meant to cover the tail of one launch with the head of the next, it costs more
+	 * than it saves (default 1). */
+	int parts = (keep_images && ctx->run_parts > 1 && !compact) ? ctx->run_parts : 1;
+	if (compact && ctx->compact_parts > 1 && n_slots >= 4000000) parts = ctx->compact_parts;
 	if (parts > PC_MAX_PARTS) parts = PC_MAX_PARTS;
 	if ((long long)parts > n_slots / 65536) parts = (int)(n_slots / 65536);
 	if (parts < 1) parts = 1;
-	ctx->n_parts = parts;
+	ctx->n_parts = compact ? 1 : parts;     /* what the fetch goes by: a compact run is fetched block by block whatever its launches */
 	const size_t rec = (size_t)PC_N_PLANES + ne;
 	int status = PC_HIP_OK;
 	hipStream_t main_stream = ctx->stream;
@@ -1854,7 +1862,7 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 	for (int k = 0; k < parts && status == PC_HIP_OK; k++) {
 		const long long lo = pc_part_begin(n_slots, parts, k), hi = pc_part_begin(n_slots, parts, k + 1);
 		a.slot0 = slot0 + lo; a.n_slots = hi - lo;
-		pc_set_img(ctx, a, lo, n_slots, keep_images != 0, planes);
+		pc_set_img(ctx, a, compact ? 0 : lo, n_slots, keep_images != 0, planes);      /* compact: positions are the run's, not the part's */
 		if (parts > 1) {
 			a.work = ctx->d_work + k;
 			ctx->stream = (k & 1) ? ctx->stream2 : main_stream;
@@ -1862,11 +1870,6 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 		if (compact) ctx->rec_ev1 = false;       /* the kernel time ends behind the tail kernel below */
 		status = ctx->host.pm.generic_src ? pc_launch_kernel<PC_MODE_SRC_GENERIC>(ctx, a, hi - lo)
 		                                  : pc_launch_kernel<PC_MODE_SRC_CIRCULAR>(ctx, a, hi - lo);
-		if (compact && status == PC_HIP_OK) {
-			hipLaunchKernelGGL(pc_compact_tail_kernel, dim3(64), dim3(256), 0, ctx->stream, ctx->d_soa, (long long)n_slots, (int)ne, ctx->d_cursor);
-			PC_HIP_CHECK(hipGetLastError());
-			PC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
-		}
 		ctx->part_end[k] = hi;
 		if (status == PC_HIP_OK && parts > 1) {
 			if (!ctx->ev_part[k]) PC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_part[k], hipEventDisableTiming));
@@ -1878,8 +1881,13 @@ int pc_hip_transmission_run(pc_hip_ctx *ctx, uint64_t seed, int64_t slot0, int64
 		/* the main stream ends after every part: wait() synchronises it, and the kernel time runs to here */
 		for (int k = 0; k < parts; k++)
 			if (k & 1) PC_HIP_CHECK(hipStreamWaitEvent(main_stream, ctx->ev_part[k], 0));
-		PC_HIP_CHECK(hipEventRecord(ctx->ev1, main_stream));
 	}
+	if (compact && status == PC_HIP_OK) {
+		hipLaunchKernelGGL(pc_compact_tail_kernel, dim3(64), dim3(256), 0, main_stream, ctx->d_soa, (long long)n_slots, (int)ne, ctx->d_cursor);
+		PC_HIP_CHECK(hipGetLastError());
+	}
+	if ((parts > 1 || compact) && status == PC_HIP_OK)
+		PC_HIP_CHECK(hipEventRecord(ctx->ev1, main_stream));
 	if (status) return status;
 	ctx->run_slots = n_slots;
 	ctx->run_pending = 1;

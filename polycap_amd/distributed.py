@@ -59,6 +59,22 @@ def allreduce_totals(vec, device=None):
     return t.cpu().numpy()
 
 
+def ranks_report(mean_kernel_ms, device=None):
+    """What a multi-rank bench line says about the job itself: how many ranks the collective saw, over which backend, and the
+    spread of the ranks' mean kernel times (one all-gather outside the timed region).  None without a process group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    world = dist.get_world_size()
+    mine = torch.tensor([float(mean_kernel_ms)], dtype=torch.float64, device=device if device is not None else "cpu")
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    per_rank = [float(x.item()) for x in every]
+    return {"world_size": world, "backend": dist.get_backend(), "ranks_seen": len(per_rank),
+            "per_rank_kernel_ms": [min(per_rank), max(per_rank)]}
+
+
 def efficiencies_from_totals(counters, sums):
     """Efficiency formula of the reference (src/polycap-source.c:1066-1076)."""
     iexit, not_entered, not_trans = int(counters[0]), int(counters[1]), int(counters[2])

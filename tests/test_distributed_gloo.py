@@ -50,7 +50,8 @@ def _worker(rank, world, port, n_total, seed, out_q):
     try:
         _, _, prob, _ = make_pair(O, "ellip", energies=(8.0, 10.0))
         r = pcd.run_sharded(prob, seed, n_total, rank=rank, world_size=world, trace_fn=_oracle_trace_fn())
-        out_q.put((rank, r["counters"].tolist(), [str(v) for v in r["sumw_exact"]], r["efficiencies"].tolist(), r["slot0"], r["n_local"]))
+        rep = pcd.ranks_report(10.0 + rank)             # what bench.py prints as "rccl" under N > 1
+        out_q.put((rank, r["counters"].tolist(), [str(v) for v in r["sumw_exact"]], r["efficiencies"].tolist(), r["slot0"], r["n_local"], rep))
     finally:
         dist.destroy_process_group()
 
@@ -91,13 +92,16 @@ def test_two_rank_gloo_equals_single_rank():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, seed, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=300) for _ in procs)
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     _, _, prob, _ = make_pair(O, "ellip", energies=(8.0, 10.0))
     single = pcd.run_sharded(prob, seed, n_total, trace_fn=_oracle_trace_fn())
-    for rank, counters, exact, eff, slot0, n_local in res:
+    for rank, counters, exact, eff, slot0, n_local, rep in res:
+        # the "rccl" block of a multi-rank bench line (bench.py under N > 1): every rank saw both ranks and the spread of their
+        # kernel times
+        assert rep == {"world_size": 2, "backend": "gloo", "ranks_seen": 2, "per_rank_kernel_ms": [10.0, 11.0]}
         assert counters == single["counters"].tolist()
         assert exact == [str(v) for v in single["sumw_exact"]]
         assert eff == single["efficiencies"].tolist()
