@@ -33,12 +33,21 @@
  *     energy and reflection (25 of 71 instructions), and one rounding of the device's 6e-15 exponential instead of one per
  *     reflection.  With roughness the weights therefore equal those of the immediate sweep to ~1e-14, not bit for bit; where a
  *     log is cut depends on the photon alone, so a photon's weights do not depend on scheduling, partition or device count.
- *   dead weights (histogram-only runs).  Totals are exact sums of floor(w 2^62).  A weight below 2^-64 contributes 0, and,
- *     every later factor of a tame log being < 1, stays below: a pass stops once all its 64 weights are there (tested every
- *     eighth reflection).  The sums are the same integers; runs that keep images multiply every weight to the end.
+ *   fused finalisation, dead weights (histogram-only runs).  A photon that has reached the exit window with a live proxy is alive
+ *     at the end of its log, so its sweep adds its weights to the exact LDS sums itself: no weight row is written for it and
+ *     none read back by the NEW phase.  Should the sweep find it dead all the same, a second pass over its items takes the sums
+ *     back exactly (a.sweep_fuse = 2 fuses whatever the proxies say: the tests' way to that pass).  Totals are exact sums of
+ *     floor(w 2^62): a weight below 2^-64 contributes 0 and, every later factor of a tame log being < 1, stays below: a pass
+ *     stops once all its 64 weights are there (tested every eighth reflection).  Runs that keep images multiply every weight to
+ *     the end and hand the rows to the NEW phase.
+ *   gathered sweeps.  A pass takes 64 (photon, energy) pairs and the last pass of a round is seldom full (291 energies: 9 % of a
+ *     lone photon's lanes idle, 2.6 % for three photons): finished photons and lanes with a full log wait until a.flush_min of
+ *     them can be swept together (or nothing else can run); up to a.stage_ps logs are staged in LDS per round.
  *   slots.  Waves take chunks of 128 slots from one counter; once fewer than 128 per wave are left a request is served with
  *     its share of the rest (lanes that get none retire), so that the launch does not end with some waves still holding a
- *     hundred photons and the others none: the sweeps, 92 % of the work, are as efficient for one photon as for sixty-four.
+ *     hundred photons and the others none: the sweeps, 92 % of the work, are as efficient for three photons as for sixty-four.
+ *   registers.  Two waves per SIMD (512-thread workgroups), 239 registers, no scratch; the FAST loop evaluates two reflections
+ *     per step as two interleaved dependent chains (pc_fresnel3xN).
  */
 #ifndef PCS_BLOCK
 #define PCS_BLOCK 512          /* 8 waves per CU, 2 per SIMD: 256 registers per lane (at 3 per SIMD and 168 registers a hundred of them lived in

@@ -564,6 +564,30 @@ def test_logged_reflections_with_photons_that_die(pa, oracle):
     o = oracle.transmission(optic, src, E, A, S, 5, 0, 20000)
     with pa.TraceContext(prob) as ctx:
         t = ctx.transmission(5, 0, 20000)
+        # slots that use up their attempts (two per slot here): the same failed slots, counters and sums from both kernels, with the
+        # slot-ordered image store and with the compact one (whose positions behind the cursor are zeroed)
+        res = {}
+        for b in (0, 1):
+            ctx.set_option("batch_reflections", b)
+            ctx.run(9, 100, 30000, max_attempts=2, keep_images=True)
+            ctx.wait()
+            res[b] = (ctx.totals(check=False), ctx.images(0, 30000))
+        assert res[0][0]["failed_slots"] > 1000
+        assert np.array_equal(res[0][0]["counters"], res[1][0]["counters"]) and np.array_equal(res[0][0]["sumw_fixed"], res[1][0]["sumw_fixed"])
+        done = res[0][1]["exit_weights"].max(axis=1) > 0
+        assert np.array_equal(done, res[1][1]["exit_weights"].max(axis=1) > 0)
+        assert np.array_equal(res[0][1]["exit_weights"], res[1][1]["exit_weights"])
+        assert np.array_equal(res[0][1]["images"][done], res[1][1]["images"][done], equal_nan=True)
+        ctx.set_option("plane_images", 1)
+        ctx.set_option("compact_images", 1)
+        ctx.run(9, 100, 30000, max_attempts=2, keep_images=True)
+        ctx.wait()
+        tc = ctx.totals(check=False)
+        pl = ctx.image_planes(0, 30000)
+        assert np.array_equal(tc["counters"], res[1][0]["counters"]) and np.array_equal(tc["sumw_fixed"], res[1][0]["sumw_fixed"])
+        n_ok = int(tc["i_exit"])
+        assert n_ok == int(done.sum()) and np.all(pl["exit_weights"][n_ok:] == 0.) and np.all(pl["planes"][:, n_ok:] == 0.)
+        assert np.all(pl["exit_weights"][:n_ok].max(axis=1) >= 1e-4)
     assert np.all(np.abs(t["efficiencies"] - o["efficiencies"]) <= 1.5 / np.sqrt(o["i_start"]) * o["efficiencies"] + 1e-12)
     assert abs(t["not_transmitted"] - o["not_transmitted"]) <= 4 * np.sqrt(o["not_transmitted"])
 
