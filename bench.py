@@ -520,6 +520,7 @@ def cpu_baseline(prob, args, ctx):
             "exit_photons_per_s": o["i_exit"] / dt,
             "efficiency_cpu": float(o["efficiencies"][0]), "efficiency_gpu_same_slots": float(g["efficiencies"][0]),
             "eff_rel_delta": abs(float(g["efficiencies"][0]) - float(o["efficiencies"][0])) / float(o["efficiencies"][0]),
+            "eff_rel_delta_one_sigma_at_this_n": 0.48 / float(o["i_start"]) ** 0.5,      # measured noise constant of identical-seed runs (parity_fixture)
             "eff_delta_note": "identical seeds on a %.1e-photon sample; the trace is chaotic, so the delta falls as ~0.6/sqrt(N): "
                               "at N = 2.4e8 it is below 1e-4 (profiles/r02/parity_1e8.json, tests/test_parity_fixture.py)" % o["i_start"]}
 
