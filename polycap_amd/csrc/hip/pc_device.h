@@ -770,7 +770,7 @@ PC_HD int pc_reflect_energy(const pc_energy_const &ec, const pc_refl_geom &g, do
  *   - on the device the two roots come from v_rsq_f64 and the quotient from v_rcp_f64 (2^-24, scripts/analysis/fp64_rates.hip)
  *     with one Newton step each (~4e-15 relative); |z|^2 >= zi2 >= 2^-200 keeps them finite.  The host compile evaluates
  *     the same expressions with IEEE sqrt and division.
- * 46 instructions per energy and reflection (FORM 2, round 3: 57).  The weights differ from FORMs 0/1 by the reference's own
+ * 45 instructions per energy and reflection (FORM 2, round 3: 57).  The weights differ from FORMs 0/1 by the reference's own
  * rounding noise (~1e-10 relative near the critical angle, where 1 - sin^2/n^2 cancels); the trajectory does not depend on
  * them.  Callers guarantee ec.valid != 0 (runs with an invalid energy keep FORM 1). */
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -837,15 +837,18 @@ PC_HD void pc_refl_geom3(const pc_refl_geom &g, double &c2, double &fs, double &
 	fs = g.es2/g.sd2;
 	fp = g.ep2/g.sd2;
 }
+#define PC_SQRT2 1.41421356237309504880
+/* cos(theta) sqrt(2): FORM 3 carries everything multiplied by S = sqrt(2Q) = sqrt(2) sqrt(Q); the constant factor goes to the
+ * cosine once per reflection instead of to Q once per energy */
+PC_HD double pc_refl_cr2(double c) { return c*PC_SQRT2; }
 
-/* rtot of one energy: d2, n2r, n2i, zi2 from pc_energy_const; c = cos(theta) (>= 0), c2, fs, fp from pc_refl_geom3 */
-PC_HD double pc_fresnel3(double d2, double n2r, double n2i, double zi2, double c, double c2, double fs, double fp)
+/* rtot of one energy: d2, n2r, n2i, zi2 from pc_energy_const; cr2 = cos(theta) sqrt(2) (pc_refl_cr2), c2, fs, fp from pc_refl_geom3 */
+PC_HD double pc_fresnel3(double d2, double n2r, double n2i, double zi2, double cr2, double c2, double fs, double fp)
 {
 	const double zr = c2 - d2;
 	const double mag = pc_sqrt_fast(fma(zr, zr, zi2));
 	const double Q = mag + fabs(zr);
-	const double S = pc_sqrt_fast(Q + Q);
-	const double cS = c*S;
+	const double cS = cr2*pc_sqrt_fast(Q);                   /* cos(theta) S, S = sqrt(2Q) */
 	const bool up = zr >= 0.;
 	const double Gr = up ? Q : n2i, Gi = up ? n2i : Q;
 	const double nr = cS - Gr, dr = cS + Gr;
@@ -859,7 +862,7 @@ PC_HD double pc_fresnel3(double d2, double n2r, double n2i, double zi2, double c
 
 /* N reflections of one energy at once (the FAST loop of pc_trace_log_kernel): the same operations as N calls of pc_fresnel3,
  * written step by step for all of them so that the device compiler issues the N dependent chains alternately (its scheduler
- * would run them one after the other; a scheduling barrier after every step keeps the order written here).  in[k] = {c, c2,
+ * would run them one after the other; a scheduling barrier after every step keeps the order written here).  in[k] = {cr2, c2,
  * fs, fp} of reflection k.  Bit-identical to the single evaluation. */
 #if PC_FAST_MATH_DEVICE
 #define PC_CHAIN_STEP() __builtin_amdgcn_sched_barrier(0)
@@ -880,9 +883,8 @@ PC_HD void pc_fresnel3xN(double d2, double n2r, double n2i, double zi2, const do
 	PC_EACH(r[k] = fma(-h[k], g[k], 0.5));
 	PC_EACH(g[k] = fma(g[k], r[k], g[k]));                   /* |z| */
 	PC_EACH(Q[k] = g[k] + fabs(zr[k]));
-	PC_EACH(m2[k] = Q[k] + Q[k]);
-	PC_EACH(y[k] = __builtin_amdgcn_rsq(m2[k]));
-	PC_EACH(g[k] = m2[k]*y[k]);
+	PC_EACH(y[k] = __builtin_amdgcn_rsq(Q[k]));
+	PC_EACH(g[k] = Q[k]*y[k]);
 	PC_EACH(h[k] = 0.5*y[k]);
 	PC_EACH(r[k] = fma(-h[k], g[k], 0.5));
 	PC_EACH(S[k] = fma(g[k], r[k], g[k]));
@@ -923,7 +925,7 @@ PC_HD void pc_fresnel3xN(double d2, double n2r, double n2i, double zi2, const do
  * Same return values as pc_reflect_energy_f. */
 PC_HD int pc_reflect_energy3(const pc_energy_const &ec, double c, double c2, double fs, double fp, double &w)
 {
-	const double rt = pc_fresnel3(ec.d2, ec.n2_re, ec.n2_im, ec.zi2, c, c2, fs, fp);
+	const double rt = pc_fresnel3(ec.d2, ec.n2_re, ec.n2_im, ec.zi2, pc_refl_cr2(c), c2, fs, fp);
 	if (rt < 0. || rt > 1.) return -1;                          /* src/polycap-capil.c:633-637 */
 	double f = rt;
 	if (ec.rough_c != 0.) {

@@ -59,7 +59,7 @@
 #endif
 #define PCS_PITCH 1024
 #define PCS_MAXPS 16           /* photons of a wave swept in one round (their logs are staged in LDS) */
-#define PCS_ENT 4              /* doubles of a staged log entry: cos, cos^2, fs, fp */
+#define PCS_ENT 4              /* doubles of a staged log entry: cos sqrt(2), cos^2, fs, fp */
 #define PCS_DEAD 5.421010862427522e-20    /* 2^-64 */
 #ifndef PCS_CHAINS
 #define PCS_CHAINS 2           /* reflections the FAST loop takes per step (pc_fresnel3xN: that many interleaved chains) */
@@ -172,7 +172,7 @@ pc_trace_log_kernel(pc_kargs a)
 			double part = 0.;
 			for (int r = lane; r < n; r += PC_WAVE) {
 				const double c = src[3*r], c2 = c*c;
-				dst[PCS_ENT*r] = c; dst[PCS_ENT*r + 1] = c2; dst[PCS_ENT*r + 2] = src[3*r + 1]; dst[PCS_ENT*r + 3] = src[3*r + 2];
+				dst[PCS_ENT*r] = pc_refl_cr2(c); dst[PCS_ENT*r + 1] = c2; dst[PCS_ENT*r + 2] = src[3*r + 1]; dst[PCS_ENT*r + 3] = src[3*r + 2];
 				part += c2;
 			}
 			if (rough) {
@@ -217,6 +217,8 @@ pc_trace_log_kernel(pc_kargs a)
 				 * nearly always) runs two reflections per step: two independent Fresnel chains for the fp64 pipe */
 				int r = 0;
 				if (PCS_CHAINS > 1 && __builtin_amdgcn_ballot_w64(act && n != n_pass) == 0ull) {
+					/* (reading the next step's entries from LDS ahead of the current step's arithmetic was measured: 28.5-28.9 against
+					 * 28.1-28.4 ms, with two waves per SIMD the other wave covers the LDS latency already: profiles/r04/kernel_history.md) */
 					for (; r + PCS_CHAINS <= n_pass; r += PCS_CHAINS) {
 						if (skip && (r & 7) + PCS_CHAINS > 7 && __builtin_amdgcn_ballot_w64(act && w >= PCS_DEAD) == 0ull) break;
 						double in[PCS_CHAINS][4], f[PCS_CHAINS];
@@ -321,10 +323,13 @@ pc_trace_log_kernel(pc_kargs a)
 			if (lim < K) lim = (PCS_LEASH < K) ? PCS_LEASH : K;       /* proxies dead, photon swept: a longer leash from here on */
 		}
 	};
-	auto flush = [&](unsigned long long mF) __attribute__((always_inline)) {
-		while (mF) {
+	/* Rounds of exactly a.flush_min photons (the count whose last pass is nearly full); what is left over waits for the next
+	 * flush unless nothing else can run (`all`) */
+	auto flush = [&](unsigned long long mF, bool all) __attribute__((always_inline)) {
+		const int per = all ? PS : a.flush_min;
+		while (mF && (all || __popcll(mF) >= per)) {
 			unsigned long long mR = 0ull, t = mF;
-			for (int k = 0; k < PS && t; k++) { mR |= t & (0ull - t); t &= t - 1ull; }
+			for (int k = 0; k < per && t; k++) { mR |= t & (0ull - t); t &= t - 1ull; }
 			mF &= ~mR;
 			sweep_round(mR);
 		}
@@ -347,13 +352,13 @@ pc_trace_log_kernel(pc_kargs a)
 				if (lim == K) {
 					{
 						const int pe = a.proxy_e[0];
-						double f = pc_fresnel3(ecs[pe], ecs[ne + pe], ecs[2*ne + pe], ecs[3*ne + pe], fr_c, c2, fs, fp);
+						double f = pc_fresnel3(ecs[pe], ecs[ne + pe], ecs[2*ne + pe], ecs[3*ne + pe], pc_refl_cr2(fr_c), c2, fs, fp);
 						if (rough) f = f*pc_exp_neg_fast(-(ecs[4*ne + pe]*c2));
 						wprox0 = wprox0*f;
 					}
 					if (a.n_proxy > 1) {
 						const int pe = a.proxy_e[1];
-						double f = pc_fresnel3(ecs[pe], ecs[ne + pe], ecs[2*ne + pe], ecs[3*ne + pe], fr_c, c2, fs, fp);
+						double f = pc_fresnel3(ecs[pe], ecs[ne + pe], ecs[2*ne + pe], ecs[3*ne + pe], pc_refl_cr2(fr_c), c2, fs, fp);
 						if (rough) f = f*pc_exp_neg_fast(-(ecs[4*ne + pe]*c2));
 						wprox1 = wprox1*f;
 					}
@@ -375,7 +380,7 @@ pc_trace_log_kernel(pc_kargs a)
 		const bool do_new = (nN >= a.new_threshold) || (nM == 0 && nE == 0);
 		const int phase = (nM > 0 && (nM >= a.event_threshold || (nE == 0 && !do_new))) ? 0 : ((nE > 0 && !(do_new && nN > nE)) ? 1 : ((nN > 0 && do_new) ? 2 : 3));
 		if (mBlk | mDn) {
-			if (__popcll(mBlk | mDn) >= a.flush_min || phase == 3) { flush(mBlk | mDn); continue; }
+			if (__popcll(mBlk | mDn) >= a.flush_min || phase == 3) { flush(mBlk | mDn, phase == 3); continue; }
 		}
 		if (phase == 0) {
 			/* ---------------- MARCH burst */
