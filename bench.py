@@ -297,13 +297,13 @@ def pmc_block(pmc_file, kernel, kernel_ms):
 
 
 def side_workload(deck_name, energies, sig_rough, n_slots, dev_index, pmc_file=None):
-    """started photons/s of another BASELINE configuration's kernel (histogram only, one warm-up + one timed run).
+    """started photons/s of another BASELINE configuration's kernel (histogram only, one warm-up launch + one timed launch of the same size).
     pmc_file: committed rocprofv3 --pmc summary of exactly this workload."""
     import polycap_amd
     path = os.path.join(ROOT, "tests", "golden", "example", deck_name + ".inp")
     prob = polycap_amd.problem_from_inp(path, energies=energies, sig_rough=sig_rough)
     with polycap_amd.TraceContext(prob, dev_index) as c:
-        c.transmission(1, 0, min(n_slots, 50_000))
+        c.transmission(1, 0, n_slots)              # one untimed warm-up launch of the same size (buffers, clocks), like the headline's warm-up steps
         t0 = time.perf_counter()
         r = c.transmission(2, 0, n_slots)
         dt = time.perf_counter() - t0

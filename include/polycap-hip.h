@@ -104,7 +104,7 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
  *   "batch_reflections" source runs with more than 32 energies: 1 (default) reflections are logged (24 B each) and a photon's
  *                      weights swept once per log, 2 round 3's kernel (four reflections wait in LDS per sweep), 0 every
  *                      reflection sweeps the weights at once
- *   "log_cap"          reflections per log of the logging kernel (default 64, 1..255)
+ *   "log_cap"          reflections per log of the logging kernel (1..255; default 0 = 64 from 64 energies on, 32 below)
  *   "sweep_skip"       histogram-only runs of the logging kernel stop multiplying a weight once it is below 2^-64 (it adds
  *                      nothing to the exact sums any more; default 1)
  *   "flush_max"        the logging kernel lets up to this many finished photons of a wave wait for a common sweep (default 8; the

@@ -935,7 +935,8 @@ struct pc_hip_ctx {
 	int lds_ec = 1;                /* many-energy runs: per-energy constants in LDS, one 1024-thread workgroup per CU */
 	int batch_reflections = 1;     /* more than 32 energies, source runs: 1 = reflections are logged and a photon's weights swept once per log
 	                                * (pc_sweep_kernel.h), 0 = every reflection sweeps the weights at once */
-	int log_cap = 64;              /* option "log_cap": reflections per log of pc_trace_log_kernel */
+	int log_cap = 0;               /* option "log_cap": reflections per log of pc_trace_log_kernel; 0 = 64 from 64 energies on, 32 below (shorter logs
+	                                * leave room in LDS for the logs of more photons per sweep, which few energies need to fill their passes) */
 	int sweep_skip = 1;            /* option "sweep_skip": histogram-only log runs stop multiplying a weight below 2^-64 */
 	int flush_max = 8;             /* option "flush_max": at most this many finished photons of a wave wait for a common sweep */
 	int sweep_fuse = 1;            /* option "sweep_fuse": histogram-only log runs add a finished photon's weights to the sums in its sweep; 2 = also when
@@ -1263,7 +1264,8 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		return PC_HIP_OK;
 	}
 	if constexpr (MODE != PC_MODE_EXPLICIT) {
-		const size_t stage = want_log ? pc_log_stage_doubles(ctx, ne, ctx->log_cap) : 0;
+		const int log_cap = ctx->log_cap > 0 ? ctx->log_cap : (ne >= 64 ? 64 : 32);
+		const size_t stage = want_log ? pc_log_stage_doubles(ctx, ne, log_cap) : 0;
 		if (stage) {
 			/* reflections are logged, a photon's weights swept once per log (pc_sweep_kernel.h): one workgroup of 12 waves per CU */
 			pc_sweep_certificate(ctx);
@@ -1271,7 +1273,7 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 			int grid = (int)(want < pc_cus(ctx) ? want : pc_cus(ctx));
 			if (grid < 1) grid = 1;
 			a.total_threads = (long long)grid * PCS_BLOCK;
-			const size_t need_w = (size_t)ne * (size_t)a.total_threads, need_l = 3*(size_t)ctx->log_cap * (size_t)a.total_threads;
+			const size_t need_w = (size_t)ne * (size_t)a.total_threads, need_l = 3*(size_t)log_cap * (size_t)a.total_threads;
 			if (need_w > ctx->wscratch_elems) {
 				if (ctx->d_wscratch) PC_HIP_CHECK(hipFree(ctx->d_wscratch));
 				ctx->d_wscratch = nullptr; ctx->wscratch_elems = 0;
@@ -1286,8 +1288,8 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 			}
 			a.wscratch = ctx->d_wscratch;
 			a.rlog = ctx->d_rlog;
-			a.log_cap = ctx->log_cap;
-			a.stage_ps = (int)(stage/(PCS_ENT*(size_t)ctx->log_cap));
+			a.log_cap = log_cap;
+			a.stage_ps = (int)(stage/(PCS_ENT*(size_t)log_cap));
 			{
 				/* photons that wait for a sweep before one is run: the fewest (up to the stage's capacity) whose last pass leaves at
 				 * most 3 % of the round's lanes idle, else the count that leaves the fewest */
@@ -1480,7 +1482,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "blocks_per_cu") { if (value < 1 || value > 8) return pc_fail(PC_HIP_ERR_INVALID, "blocks_per_cu must be in [1,8]"); ctx->blocks_per_cu = (int)value; }
 	else if (n == "lds_ec") ctx->lds_ec = value ? 1 : 0;
 	else if (n == "batch_reflections") ctx->batch_reflections = value ? 1 : 0;
-	else if (n == "log_cap") { if (value < 1 || value > 255) return pc_fail(PC_HIP_ERR_INVALID, "log_cap must be in [1,255]"); ctx->log_cap = (int)value; }
+	else if (n == "log_cap") { if (value < 0 || value > 255) return pc_fail(PC_HIP_ERR_INVALID, "log_cap must be in [0,255] (0 = automatic)"); ctx->log_cap = (int)value; }
 	else if (n == "sweep_skip") ctx->sweep_skip = value ? 1 : 0;
 	else if (n == "flush_max") { if (value < 1 || value > 16) return pc_fail(PC_HIP_ERR_INVALID, "flush_max must be in [1,16]"); ctx->flush_max = (int)value; }
 	else if (n == "sweep_fuse") { if (value < 0 || value > 2) return pc_fail(PC_HIP_ERR_INVALID, "sweep_fuse must be 0, 1 or 2"); ctx->sweep_fuse = (int)value; }

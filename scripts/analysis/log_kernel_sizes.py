@@ -18,4 +18,4 @@ with polycap_amd.TraceContext(prob) as ctx:
             r = ctx.transmission(2, 0, n)
             st = ctx.sweep_stats()
             print("%s log_cap %3d: %8d slots, kernel %8.2f ms = %6.2f ms per 1e6 slots, %.4g started photons/s; passes %.3g iterations %.3g; waves finish at %.3f of the longest on average"
-                  % (deck, cap, n, r["kernel_ms"], r["kernel_ms"]*1e6/n, r["i_start"]/(r["kernel_ms"]*1e-3), st["passes"], st["iterations"], st["wave_life_sum"]/3072.0/max(1, st["wave_life_max"])), flush=True)
+                  % (deck, cap, n, r["kernel_ms"], r["kernel_ms"]*1e6/n, r["i_start"]/(r["kernel_ms"]*1e-3), st["passes"], st["iterations"], st["wave_life_sum"]/2048.0/max(1, st["wave_life_max"])), flush=True)
