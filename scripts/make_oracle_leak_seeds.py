@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Fixture: totals of the CPU oracle's leak driver (oracle/polycap_oracle_leak.c, the reference's literal algorithm:
 src/polycap-source.c:744-1087 with leak_calc, polycap_capil_trace_wall) on the reference's test optic under uniform illumination,
-for many seeds -- what tests/test_gpu_leak.py::test_leak_driver_totals_against_the_oracle_fixture needs for per-seed mean +- s.e.
-    python scripts/make_oracle_leak_seeds.py [--jobs 6]   ->  tests/golden/oracle_leak_seeds.json
+for many seeds -- what tests/test_gpu_leak.py::test_leak_driver_against_the_oracle_seed_by_seed needs for per-seed mean +- s.e.
+    python scripts/make_oracle_leak_seeds.py [--jobs 6] [--tiny out.json]   ->  tests/golden/oracle_leak_seeds.json
+(--tiny: 3 seeds x 100 slots and 2 seeds x 50 slots into out.json, to try the test's plumbing: POLYCAP_LEAK_SEEDS_FIXTURE=out.json)
 Runs: 16 seeds x 8000 exit-photon slots at 10 keV (the leak bench's workload; 6 CPU-minutes per seed) and 4 seeds x 4000 slots on
 the seven energies of the reference's source test (tests/source.c:216-222: 1, 5, 10, 15, 20, 25, 30 keV).  The optical constants
 each run used are stored with it: the device test feeds the same numbers."""
@@ -39,6 +40,7 @@ print(json.dumps({"seed": %(seed)d, "slot0": %(slot0)d, "n": %(n)d, "counters": 
 
 def main():
     jobs = int(sys.argv[sys.argv.index("--jobs") + 1]) if "--jobs" in sys.argv else 6
+    tiny = sys.argv[sys.argv.index("--tiny") + 1] if "--tiny" in sys.argv else None
     from oracle import pyoracle
     pyoracle.build()
     from tests.conftest import GOLDEN
@@ -52,6 +54,10 @@ def main():
               dict(name="seven_energies", energies=E7, amu=[float(x) for x in a7], scatf=[float(x) for x in s7],
                    seeds=list(range(30000, 30004)), n=4000)]
     block = 1000
+    if tiny:
+        groups[0]["seeds"], groups[0]["n"] = [20000, 20001, 20002], 100
+        groups[1]["seeds"], groups[1]["n"] = [30000, 30001], 50
+        block = 50
     tasks = []
     for gi, g in enumerate(groups):
         for seed in g["seeds"]:
@@ -97,7 +103,7 @@ def main():
                          "ext_weights": [sum(b["ext_weights"][e] for b in bl) for e in range(ne)],
                          "int_weights": [sum(b["int_weights"][e] for b in bl) for e in range(ne)]})
         doc["groups"].append({"name": g["name"], "energies": g["energies"], "amu": g["amu"], "scatf": g["scatf"], "runs": runs})
-    with open(os.path.join(ROOT, "tests", "golden", "oracle_leak_seeds.json"), "w") as f:
+    with open(tiny or os.path.join(ROOT, "tests", "golden", "oracle_leak_seeds.json"), "w") as f:
         json.dump(doc, f, indent=1)
     print("written", len(tasks), "blocks")
 

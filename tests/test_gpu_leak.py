@@ -279,15 +279,18 @@ def test_leak_driver_against_the_oracle_seed_by_seed(pa, optic):
     literal algorithm -- for 16 seeds x 8000 exit-photon slots at 10 keV (the leak bench's workload) and 4 seeds x 4000 slots on
     the seven energies of the reference's source test, with the optical constants each group used.  Identical photon streams;
     the trajectories are chaotic, so the kernel agrees statistically: per quantity -- started photons,
-    efficiency, numbers and summed weights of both kinds of leak event, per energy -- the per-seed relative deltas must be
-    consistent with zero, |mean| < 3.5 standard errors (the headline's standard: tests/test_parity_fixture.py), and the noise
-    constants c = std(delta) sqrt(N_started per seed) are printed.  A bias of the certified wall search would show here."""
+    efficiency, numbers and summed weights of both kinds of leak event, per energy -- the per-seed deltas (device - oracle, in
+    units of the oracle's mean over the seeds) must be consistent with zero: |mean| below the two-sided 0.1 % point of Student's
+    t for the group's number of seeds (4.07 standard errors for 16 seeds, 12.9 for 4; the headline's fixture has 128 seeds and
+    uses 3) -- and, whatever the noise, below 1 % + that.  The noise constants c = std(delta) sqrt(N_started per seed) are
+    printed.  A bias of the certified wall search would show here."""
     import json
     import os
+    from scipy import stats
     from tests.conftest import GOLDEN
-    path = os.path.join(GOLDEN, "oracle_leak_seeds.json")
+    path = os.environ.get("POLYCAP_LEAK_SEEDS_FIXTURE", os.path.join(GOLDEN, "oracle_leak_seeds.json"))
     if not os.path.exists(path):
-        pytest.skip("tests/golden/oracle_leak_seeds.json is missing: python scripts/make_oracle_leak_seeds.py (2.3 CPU-hours)")
+        pytest.skip("tests/golden/oracle_leak_seeds.json is missing: python scripts/make_oracle_leak_seeds.py (several CPU-hours)")
     with open(path) as f:
         fx = json.load(f)
     report = []
@@ -295,7 +298,7 @@ def test_leak_driver_against_the_oracle_seed_by_seed(pa, optic):
         E = group["energies"]
         ne = len(E)
         prob = problem(pa, optic, E, group["amu"], group["scatf"], source=tuple(fx["source"]))
-        rows = {}
+        dev, ora = {}, {}
         n_started = []
         with pa.TraceContext(prob) as ctx:
             for run in group["runs"]:
@@ -309,23 +312,32 @@ def test_leak_driver_against_the_oracle_seed_by_seed(pa, optic):
                     q["ext_w_%g" % E[e]] = (g["ext"][:, 12 + e].sum(), run["ext_weights"][e])
                     q["int_w_%g" % E[e]] = (g["int"][:, 12 + e].sum(), run["int_weights"][e])
                 for k, (a, b) in q.items():
-                    if b > 0:
-                        rows.setdefault(k, []).append(a / b - 1.0)
+                    dev.setdefault(k, []).append(float(a))
+                    ora.setdefault(k, []).append(float(b))
         K = len(group["runs"])
+        t_crit = float(stats.t.ppf(1.0 - 0.0005, K - 1))
         n_mean = float(np.mean(n_started))
-        for k, d in rows.items():
-            d = np.array(d)
-            if len(d) < K:
+        # a kind of event that hardly carries weight at an energy (extleak at 1 keV: the glass absorbs everything) has no
+        # meaningful relative delta: such quantities are compared in units of the largest summed weight of their kind instead
+        scale = {"ext_w": max(np.mean(ora["ext_w_%g" % x]) for x in E), "int_w": max(np.mean(ora["int_w_%g" % x]) for x in E)}
+        for k in dev:
+            a, b = np.array(dev[k]), np.array(ora[k])
+            unit = float(b.mean())
+            kind = k[:5] if k[:5] in scale else None
+            if kind is not None and unit < 1e-3 * scale[kind]:
+                unit = scale[kind]
+            if unit <= 0.:
+                assert np.all(a == 0.), k
                 continue
+            d = (a - b) / unit
             se = d.std(ddof=1) / np.sqrt(K)
             z = d.mean() / se if se > 0 else 0.0
-            report.append((group["name"], k, d.mean(), se, z, d.std(ddof=1) * np.sqrt(n_mean)))
-    for name, k, m, se, z, c in report:
-        print("%-15s %-12s mean %+.2e +- %.2e  z %+5.2f  c %.2f" % (name, k, m, se, z, c))
-    worst = max(report, key=lambda r: abs(r[4]))
-    assert abs(worst[4]) < 3.5, worst
-    # and nothing is off by more than a percent in the mean, whatever its noise
-    assert all(abs(r[2]) < 0.01 + 3.5 * r[3] for r in report)
+            report.append((group["name"], k, d.mean(), se, z, d.std(ddof=1) * np.sqrt(n_mean), t_crit))
+    for name, k, m, se, z, c, tc in report:
+        print("%-15s %-12s mean %+.2e +- %.2e  t %+5.2f (limit %.2f)  c %.2f" % (name, k, m, se, z, tc, c))
+    for r in report:
+        assert abs(r[4]) < r[6], r
+        assert abs(r[2]) < 0.01 + r[6] * r[3], r
 
 
 @pytest.mark.parametrize("binding", ["ctypes", "cython"])

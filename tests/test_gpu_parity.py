@@ -561,6 +561,19 @@ def test_logged_reflections_with_photons_that_die(pa, oracle):
     for r in (b, c):
         assert np.array_equal(a["counters"][:6], r["counters"][:6]) and np.array_equal(a["sumw_fixed"], r["sumw_fixed"])
     assert np.array_equal(a["exit_weights"], b["exit_weights"]) and np.array_equal(a["images"], b["images"], equal_nan=True)
+    # an elliptical, divergent, shifted source (the generic sampling path: pc_trace_log_kernel<PC_MODE_SRC_GENERIC>) and uniform illumination
+    for source in ((2000., 0.2065, 0.1, 0., 0., 0.01, -0.02, 0.9), (5., 0.01, 0.01, -1., 0., 0., 0., 0.0)):
+        _, _, p2, _ = make_pair(oracle, "ellip", energies=np.linspace(6.0, 30.0, 48), source=source)
+        with pa.TraceContext(p2) as ctx:
+            ctx.set_option("batch_reflections", 0)
+            a2 = ctx.transmission(3, 7, 20000, keep_images=True)
+            ctx.set_option("batch_reflections", 1)
+            b2 = ctx.transmission(3, 7, 20000, keep_images=True)
+            assert ctx.last_kernel() == "pc_trace_log_kernel"
+            c2 = ctx.transmission(3, 7, 20000)
+        for r in (b2, c2):
+            assert np.array_equal(a2["counters"][:6], r["counters"][:6]) and np.array_equal(a2["sumw_fixed"], r["sumw_fixed"]), source
+        assert np.array_equal(a2["exit_weights"], b2["exit_weights"]) and np.array_equal(a2["images"], b2["images"], equal_nan=True), source
     o = oracle.transmission(optic, src, E, A, S, 5, 0, 20000)
     with pa.TraceContext(prob) as ctx:
         t = ctx.transmission(5, 0, 20000)
