@@ -860,6 +860,45 @@ PC_HD double pc_fresnel3(double d2, double n2r, double n2i, double zi2, double c
 	return pc_div_fast(fma(fs*Ns, Dp, (fp*Np)*Ds), Ds*Dp);
 }
 
+/* FORM 3 with the polarisation weights as the geometry gives them (es2, ep2, sd2: no quotients of their own): what the
+ * register-weight kernels of SOURCE runs multiply with (pc_reflect<NE, true>).  A photon's trajectory does not depend on its
+ * weights, so these runs trace the same photons as with FORMs 0/1 -- counters and image planes bit for bit -- and their weights
+ * differ from the IEEE forms by the reference's own rounding noise (1e-10 relative near the critical angle) and from the host
+ * compile of this form by the device's reciprocal / reciprocal square root + Newton (4e-15 per factor).  47 instructions
+ * against ~100 of FORM 0 with its two correctly rounded square roots and two divisions.  polycap_photon_launch (explicit
+ * photons, where callers compare per photon) keeps FORMs 0/1. */
+PC_HD double pc_fresnel3s(double d2, double n2r, double n2i, double zi2, double cr2, double c2, double es2, double ep2, double sd2)
+{
+	const double zr = c2 - d2;
+	const double mag = pc_sqrt_fast(fma(zr, zr, zi2));
+	const double Q = mag + fabs(zr);
+	const double cS = cr2*pc_sqrt_fast(Q);
+	const bool up = zr >= 0.;
+	const double Gr = up ? Q : n2i, Gi = up ? n2i : Q;
+	const double nr = cS - Gr, dr = cS + Gr;
+	const double Gi2 = Gi*Gi;
+	const double Ns = fma(nr, nr, Gi2), Ds = fma(dr, dr, Gi2);
+	const double A = n2r*cS, B = n2i*cS;
+	const double pr = A - Gr, pi_ = B - Gi, er = A + Gr, ei = B + Gi;
+	const double Np = fma(pr, pr, pi_*pi_), Dp = fma(er, er, ei*ei);
+	return pc_div_fast(fma(es2*Ns, Dp, (ep2*Np)*Ds), sd2*(Ds*Dp));
+}
+
+/* one energy of one reflection with pc_fresnel3s; same return values as pc_reflect_energy_f */
+PC_HD int pc_reflect_energy_fast(const pc_energy_const &ec, const pc_refl_geom &g, double &w)
+{
+	if (ec.valid == 0.) return -1;
+	const double rt = pc_fresnel3s(ec.d2, ec.n2_re, ec.n2_im, ec.zi2, pc_refl_cr2(g.alfa), g.alfa*g.alfa, g.es2, g.ep2, g.sd2);
+	if (rt < 0. || rt > 1.) return -1;                          /* src/polycap-capil.c:633-637 */
+	double f = rt;
+	if (ec.rough_c != 0.) {
+		const double c1 = ec.rough_c*g.alfa;
+		f = rt*pc_exp_neg_fast(-c1*c1);
+	}
+	w = w*f;
+	return (w >= 1.e-4) ? 1 : 0;
+}
+
 /* N reflections of one energy at once (the FAST loop of pc_trace_log_kernel): the same operations as N calls of pc_fresnel3,
  * written step by step for all of them so that the device compiler issues the N dependent chains alternately (its scheduler
  * would run them one after the other; a scheduling barrier after every step keeps the order written here).  in[k] = {cr2, c2,
@@ -938,7 +977,7 @@ PC_HD int pc_reflect_energy3(const pc_energy_const &ec, double c, double c2, dou
 
 /* whole reflection for one lane: geometry, all energies in order (stopping at the first error like the reference),
  * new electric vector.  Returns 1 keep, 0 absorbed, -1 error. */
-template <int NE>
+template <int NE, bool FASTF = false>
 PC_HD int pc_reflect(const pc_params &Pm, const pc_energy_const *EC, pc_photon<NE> &ph,
                      double nx, double ny, double nz)
 {
@@ -967,7 +1006,8 @@ PC_HD int pc_reflect(const pc_params &Pm, const pc_energy_const *EC, pc_photon<N
 	}
 	for (int e = 0; e < ne; e++) {
 		double we = (NE > 0) ? ph.w[NE > 0 ? e : 0] : (ph.wset ? ph.wmem[e*ph.wstride] : 1.0);
-		int r = (NE == 1) ? pc_reflect_energy_f<0>(EC[e], g, we) : ((NE > 1) ? pc_reflect_energy_f<1>(EC[e], g, we) : pc_reflect_energy(EC[e], g, we, ne == 1));
+		int r = (FASTF && NE > 0) ? pc_reflect_energy_fast(EC[e], g, we)
+		      : ((NE == 1) ? pc_reflect_energy_f<0>(EC[e], g, we) : ((NE > 1) ? pc_reflect_energy_f<1>(EC[e], g, we) : pc_reflect_energy(EC[e], g, we, ne == 1)));
 		if (r < 0) return -1;
 		if (NE > 0) ph.w[NE > 0 ? e : 0] = we; else ph.wmem[e*ph.wstride] = we;
 		keep |= r;
@@ -1079,13 +1119,14 @@ PC_HD int pc_event_post(const pc_params &Pm, pc_photon<NE> &ph, const pc_hit &h,
 	return PC_ST_MARCH;
 }
 
-template <int NE>
+/* FASTF: the weights of a register-weight kernel are multiplied with pc_fresnel3s (source runs) instead of FORMs 0/1 */
+template <int NE, bool FASTF = false>
 PC_HD int pc_event(const pc_tables &T, const pc_params &Pm, const pc_energy_const *EC, pc_photon<NE> &ph)
 {
 	pc_hit h;
 	int st = pc_event_pre(T, Pm, ph, h);
 	if (st != PC_ST_REFLECT) return st;
-	int r = pc_reflect(Pm, EC, ph, h.nx, h.ny, h.nz);
+	int r = pc_reflect<NE, FASTF>(Pm, EC, ph, h.nx, h.ny, h.nz);
 	return pc_event_post(Pm, ph, h, r);
 }
 

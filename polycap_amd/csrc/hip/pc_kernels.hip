@@ -363,7 +363,7 @@ pc_trace_kernel(pc_kargs a)
 			st_event += 1; st_event_l += (unsigned)nE;
 			if (NE > 0) {
 				if (state == LS_EVENT)
-					state = pc_event(T, Pm, a.ec, ph);
+					state = pc_event<NE, !EXPLICIT>(T, Pm, a.ec, ph);      /* source runs: pc_fresnel3s (pc_device.h) */
 			} else {
 				/* many energies: geometry per lane, then the wave sweeps each pending photon's weights with all 64
 				 * lanes over energies (coalesced, full lane utilisation whatever the number of pending photons) */

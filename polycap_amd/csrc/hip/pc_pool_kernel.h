@@ -204,7 +204,7 @@ pc_trace_pool_kernel(pc_kargs a)
 			/* ---------------- EVENT */
 			st_event += 1; st_event_l += (unsigned)__popcll(__ballot(L.state == LS_EVENT));
 			if (L.state == LS_EVENT)
-				L.state = pc_event(T, Pm, a.ec, ph);
+				L.state = pc_event<1, true>(T, Pm, a.ec, ph);
 			/* The wave is now full of flights that have just begun, most of them a few steps long: their first steps are taken
 			 * here, at the EVENT phase's lane count, instead of in a MARCH burst after an exchange with the pool. */
 			if (a.event_march > 0) {

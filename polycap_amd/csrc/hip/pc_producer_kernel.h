@@ -435,7 +435,7 @@ pc_trace_producer_kernel(pc_kargs a)
 				/* ---------------- EVENT */
 				st_event += 1; st_event_l += (unsigned)nE;
 				if (state == LS_EVENT)
-					state = pc_event(T, Pm, a.ec, ph);
+					state = pc_event<1, true>(T, Pm, a.ec, ph);
 			} else if (nN > 0) {
 				/* ---------------- NEW: finalise finished photons, pop launched ones */
 				st_new += 1; st_new_l += (unsigned)nN;

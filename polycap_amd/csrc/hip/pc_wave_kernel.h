@@ -51,7 +51,7 @@ pc_trace_wave_kernel(pc_kargs a)
 			while (st != PC_ST_DONE) {
 				if (st == PC_ST_EVENT) {
 					st_event++;
-					st = pc_event(T, Pm, a.ec, ph);
+					st = pc_event<1, true>(T, Pm, a.ec, ph);
 					continue;
 				}
 				if (ph.i >= nmax) { ph.rc = 1; st = PC_ST_DONE; break; }

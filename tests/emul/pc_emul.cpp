@@ -39,7 +39,8 @@ int setup(const pc_hip_problem *p, int literal, Emul &E)
 	return 0;
 }
 
-template <int NE>
+/* FASTF: the weights as the kernels of source runs form them (pc_fresnel3s; explicit launches keep FORMs 0/1) */
+template <int NE, bool FASTF = false>
 int run_photon(const Emul &E, pc_photon<NE> &ph, double x, double y, double z, double dx, double dy, double dz,
                double ex, double ey, double ez, int64_t *stats)
 {
@@ -49,7 +50,7 @@ int run_photon(const Emul &E, pc_photon<NE> &ph, double x, double y, double z, d
 			st = pc_march_step(E.T, E.t.pm, ph);
 			if (stats && st == PC_ST_MARCH) stats[0]++;
 		} else {
-			st = pc_event(E.T, E.t.pm, E.t.ec.data(), ph);
+			st = pc_event<NE, FASTF>(E.T, E.t.pm, E.t.ec.data(), ph);
 			if (stats) stats[1]++;
 		}
 	}
@@ -218,7 +219,7 @@ int emul_transmission(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int
 				if (E.t.pm.generic_src) pc_sample_photon<true>(E.t.pm, seed, (uint64_t)(slot0 + j), attempt, s);
 				else pc_sample_photon<false>(E.t.pm, seed, (uint64_t)(slot0 + j), attempt, s);
 				pc_photon<1> ph; ph.wmem = nullptr; ph.wstride = 0;
-				int rc = run_photon(E, ph, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez, nullptr);
+				int rc = run_photon<1, true>(E, ph, s.x, s.y, s.z, s.dx, s.dy, s.dz, s.ex, s.ey, s.ez, nullptr);
 				int ok = 0;
 				if (rc == 0) c2++;
 				else if (rc == 2) c1++;
