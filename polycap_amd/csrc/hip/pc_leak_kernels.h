@@ -576,7 +576,7 @@ static int pc_leak_collect(pc_hip_ctx *ctx, long long n_slots, bool explicit_mod
 	if ((long long)cur[0] > ctx->leak_capacity_used) { *needed = (long long)cur[0]; return 1; }
 	const size_t ne = (size_t)ctx->host.pm.n_energies, stride = PC_LR_HDR + ne, ostride = PC_HIP_LEAK_HDR + ne, n = (size_t)cur[0];
 	if (n == 0) return PC_HIP_OK;
-	if (n >= (1ull << 32) - 2) return pc_fail(PC_HIP_ERR_INVALID, "leak run: more than 2^32 event records in one run; trace the slots in several runs");
+	if (n >= (1ull << 31) - 2) return pc_fail(PC_HIP_ERR_INVALID, "leak run: more than 2^31 event records in one run (the sorts count in int); trace the slots in several runs");
 	hipStream_t st = ctx->stream;
 	const int end_bit = 64;
 	/* temporary storage of the library calls: the largest of the three sorts and the prefix sum */
