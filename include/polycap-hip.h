@@ -102,9 +102,10 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
  *   "leak_heavy_lanes", "leak_heavy_every"   which lanes the heaviest slots go to: lanes 0 .. n-1 of every m-th wave (defaults 1, 1)
  *   "leak_slot_units"  leak_calc source runs keep the units of work per slot (pc_hip_leak_slot_units)
  *   "batch_reflections" source runs with more than 32 energies: 1 (default) reflections are logged (24 B each) and a photon's
- *                      weights swept once per log, 2 round 3's kernel (four reflections wait in LDS per sweep), 0 every
- *                      reflection sweeps the weights at once
- *   "log_cap"          reflections per log of the logging kernel (1..255; default 0 = 64 from 64 energies on, 32 below)
+ *                      weights swept once per log (any energy count whose sums and constants leave room in LDS for a log per
+ *                      wave: to ~1400), 0 every reflection sweeps the weights at once
+ *   "log_cap"          reflections per log of the logging kernel (1..255; default 0 = 64 from 64 energies on, 32 below, halved
+ *                      while a log per wave does not fit beside the constants of more than ~450 energies)
  *   "sweep_skip"       histogram-only runs of the logging kernel stop multiplying a weight once it is below 2^-64 (it adds
  *                      nothing to the exact sums any more; default 1)
  *   "flush_max"        the logging kernel lets up to this many finished photons of a wave wait for a common sweep (default 8; the

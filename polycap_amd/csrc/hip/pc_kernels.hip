@@ -1206,7 +1206,8 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 	}
 	/* source runs with more than 32 (valid) energies log their reflections (pc_trace_log_kernel); an explicit photon reports its
 	 * state at the absorbing reflection, which the logging kernel's speculation overwrites */
-	const bool want_log = a.lds_ec && ne > 32 && ctx->batch_reflections && all_valid && MODE != PC_MODE_EXPLICIT;
+	const bool want_log = kne == 0 && ctx->lds_ec && ctx->host.pm.nmax + 1 <= 1024 && ne > 32 && ctx->batch_reflections && all_valid
+	                      && MODE != PC_MODE_EXPLICIT;
 	if constexpr (MODE != PC_MODE_EXPLICIT) {
 #ifdef PC_EXPERIMENTS
 		if (ctx->wave_per_photon && ne == 1 && !a.keep_images && ctx->host.pm.nmax + 1 <= 1024) {
@@ -1264,8 +1265,14 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		return PC_HIP_OK;
 	}
 	if constexpr (MODE != PC_MODE_EXPLICIT) {
-		const int log_cap = ctx->log_cap > 0 ? ctx->log_cap : (ne >= 64 ? 64 : 32);
-		const size_t stage = want_log ? pc_log_stage_doubles(ctx, ne, log_cap) : 0;
+		/* log capacity: 64 reflections (32 below 64 energies), halved while not even one log per wave fits in the stage beside
+		 * the constants of very many energies (beyond ~450) */
+		int log_cap = ctx->log_cap > 0 ? ctx->log_cap : (ne >= 64 ? 64 : 32);
+		size_t stage = want_log ? pc_log_stage_doubles(ctx, ne, log_cap) : 0;
+		while (want_log && !stage && ctx->log_cap <= 0 && log_cap > 8) {
+			log_cap /= 2;
+			stage = pc_log_stage_doubles(ctx, ne, log_cap);
+		}
 		if (stage) {
 			/* reflections are logged, a photon's weights swept once per log (pc_sweep_kernel.h): one workgroup of 12 waves per CU */
 			pc_sweep_certificate(ctx);

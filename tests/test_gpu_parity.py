@@ -544,6 +544,29 @@ def test_logged_reflections_equal_the_immediate_sweep(pa):
                         assert np.nanmax(np.abs(b["exit_weights"] - a["exit_weights"]) / a["exit_weights"]) < 1e-13, (deck, cap)
 
 
+def test_logged_reflections_over_the_range_of_energy_counts(pa):
+    """The logging kernel serves every energy count above 32 whose sums and constants leave room in LDS for one log per wave: 33,
+    449 (the immediate kernel's constants no longer fit in LDS there, it reads them from memory), 1000 (the log capacity is halved
+    to fit beside 56 KB of sums and constants).  Counters and exact sums equal the immediate sweep's; images kept at 1000."""
+    import os
+    from tests.conftest import EXAMPLE
+    for ne in (33, 449, 1000):
+        prob = pa.problem_from_inp(os.path.join(EXAMPLE, "xos1.inp"), energies=np.linspace(2.0, 40.0, ne))
+        with pa.TraceContext(prob) as ctx:
+            keep = ne == 1000
+            ctx.set_option("batch_reflections", 0)
+            a = ctx.transmission(5, 3, 12000, keep_images=keep)
+            assert ctx.last_kernel() == "pc_trace_kernel"
+            ctx.set_option("batch_reflections", 1)
+            b = ctx.transmission(5, 3, 12000, keep_images=keep)
+            assert ctx.last_kernel() == "pc_trace_log_kernel", ne
+            assert np.array_equal(a["counters"][:6], b["counters"][:6]), ne
+            assert np.array_equal(a["sumw_fixed"], b["sumw_fixed"]), ne
+            if keep:
+                assert np.array_equal(a["exit_weights"], b["exit_weights"])
+                assert np.array_equal(a["images"], b["images"], equal_nan=True)
+
+
 def test_logged_reflections_with_photons_that_die(pa, oracle):
     """The logging kernel on grids whose photons are absorbed (10-30 keV: every energy falls below 1e-4 within a few steep
     reflections): the lane's proxy energy triggers the sweep that ends the photon where the immediate sweep ends it -- counters
