@@ -243,8 +243,9 @@ int emul_transmission(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int
 }
 
 /* Analysis aid (scripts/analysis/flight_stats.py): how the march steps of a run distribute over flights.  hist[256]: flights
- * by number of march steps (last bin: >= 255); steps_by[8]: steps that advanced by 1 / PC_L1 / PC_L2 segments, probes that
- * failed at stride PC_L2 / PC_L1 (the stride is lowered), steps that ended in an EVENT, first-segment steps, flights. */
+ * by number of march steps (last bin: >= 255); steps_by[10]: steps that advanced by 1 / PC_L1 / PC_L2 segments, probes that
+ * failed at stride PC_L2 / PC_L1 (the stride is lowered), steps that ended in an EVENT without advancing, first-segment steps,
+ * flights, EVENT phases (literal visits), literal visits without a hit. */
 static int64_t dbg_adv1_lvcap, dbg_adv1_end, dbg_first_flight;
 int emul_flight_stats(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int64_t n_slots, int64_t *hist, int64_t *steps_by)
 {
@@ -252,7 +253,7 @@ int emul_flight_stats(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int
 	int r = setup(p, 0, E);
 	if (r) return r;
 	for (int k = 0; k < 256; k++) hist[k] = 0;
-	for (int k = 0; k < 8; k++) steps_by[k] = 0;
+	for (int k = 0; k < 10; k++) steps_by[k] = 0;
 	for (int64_t j = 0; j < n_slots; j++) {
 		for (uint32_t attempt = 0; attempt < (1u << 20); attempt++) {
 			pc_start s;
@@ -266,7 +267,7 @@ int emul_flight_stats(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int
 					const int i0 = ph.i, first = ph.first, lv0 = ph.lv;
 					const double C0b = ph.C0;
 					st = pc_march_step(E.T, E.t.pm, ph);
-					if (getenv("PC_FS_TRACE") && j < 3) {
+										if (getenv("PC_FS_TRACE") && j < 3) {
 						const pc_marg4 g = E.T.mg[i0];
 						const float knf = (float)ph.kn;
 						fprintf(stderr, "slot %lld refl %d: i %d first %d cap %d C0 %.3e  m1 %.3e m2 %.3e (md1 %.2e r2 %.2e kn %.1f) -> i %d cap %d st %d\n", (long long)j, ph.irefl, i0, first, lv0, C0b,
@@ -275,7 +276,7 @@ int emul_flight_stats(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int
 					in_flight++;
 					if (ph.irefl == 0) dbg_first_flight++;
 					if (first) steps_by[6]++;
-					else if (st == PC_ST_MARCH) {
+					else if (st == PC_ST_MARCH || ph.i != i0) {      
 						const int adv = ph.i - i0;
 						if (adv == 1) { steps_by[0]++; if (getenv("PC_FS_DEBUG") && ph.lv > 0) dbg_adv1_lvcap++; if (getenv("PC_FS_DEBUG") && i0 + PC_L1 > E.t.pm.nmax) dbg_adv1_end++; }
 						else if (adv == PC_L1) steps_by[1]++;
@@ -284,6 +285,8 @@ int emul_flight_stats(const pc_hip_problem *p, uint64_t seed, int64_t slot0, int
 					} else if (st == PC_ST_EVENT) steps_by[5]++;
 				} else {
 					st = pc_event(E.T, E.t.pm, E.t.ec.data(), ph);
+					steps_by[8]++;
+					if (st == PC_ST_MARCH && !ph.first) steps_by[9]++;      /* literal visit without a hit */
 					if (ph.first || st == PC_ST_DONE) {      /* a reflection (a new flight begins) or the end */
 						hist[in_flight < 255 ? in_flight : 255]++;
 						steps_by[7]++;

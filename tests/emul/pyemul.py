@@ -86,11 +86,11 @@ def transmission(problem, seed, slot0, n_slots, max_attempts=1 << 20, n_threads=
 def flight_stats(problem, seed, slot0, n_slots):
     """Histogram of march steps per flight and the kinds of steps (analysis aid, see emul_flight_stats)."""
     hist = np.zeros(256, dtype=np.int64)
-    by = np.zeros(8, dtype=np.int64)
+    by = np.zeros(10, dtype=np.int64)
     r = lib().emul_flight_stats(C.byref(problem.s), seed, slot0, n_slots, hist.ctypes.data_as(c_int64_p), by.ctypes.data_as(c_int64_p))
     if r:
         raise RuntimeError("emul_flight_stats failed: %d" % r)
-    return hist, dict(zip(("adv1", "advL1", "advL2", "failL2", "failL1", "to_event", "first", "flights"), by.tolist()))
+    return hist, dict(zip(("adv1", "advL1", "advL2", "failL2", "failL1", "to_event", "first", "flights", "events", "event_misses"), by.tolist()))
 
 
 def sample(problem, seed, slots, attempts):
