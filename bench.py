@@ -262,6 +262,16 @@ def pmc_summary(n_local, keep_images, kernel):
     return summary
 
 
+def simd_valu_busy(pmc):
+    """Share of the kernel's cycles in which a SIMD's vector ALU is executing an instruction, from the counters alone:
+    SQ_ACTIVE_INST_VALU counts 4-cycle steps summed over waves, SQ_BUSY_CYCLES the kernel's cycles summed over the 32 shader
+    engines (checked against the kernel time of four profiled kernels: SQ_BUSY_CYCLES / 32 = duration x 2.0-2.2 GHz), the chip
+    has 1024 SIMDs: 4 A / (1024 B / 32) = A / (8 B).  No clock frequency enters."""
+    if not pmc or "SQ_ACTIVE_INST_VALU" not in pmc or not pmc.get("SQ_BUSY_CYCLES"):
+        return None
+    return pmc["SQ_ACTIVE_INST_VALU"] / (8.0 * pmc["SQ_BUSY_CYCLES"])
+
+
 def valu_issue(pmc, kernel_ms):
     """VALU issue rate of the trace kernel: wave-instructions per launch (SQ_INSTS_VALU of the committed PMC summary) over
     the live kernel time, against the chip's issue peak.  This, not HBM, is the resource the kernel saturates."""
@@ -270,6 +280,7 @@ def valu_issue(pmc, kernel_ms):
     rate = pmc["SQ_INSTS_VALU"] / (kernel_ms * 1e-3)
     return {"wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "achieved_per_s": rate, "peak_per_s": VALU_ISSUE_PEAK,
             "frac": rate / VALU_ISSUE_PEAK,
+            "simd_valu_busy": simd_valu_busy(pmc),
             "lane_utilisation": pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]),
             "source": os.path.relpath(PMC_SUMMARY, ROOT) + " (rocprofv3 --pmc) / HIP-event kernel time of this run"}
 
@@ -288,7 +299,7 @@ def pmc_block(pmc_file, kernel, kernel_ms):
         return {"mismatch": "summary %s is of %r, this leg ran %r" % (pmc_file, named, kernel)}
     rate = pmc["SQ_INSTS_VALU"] / (kernel_ms * 1e-3)
     return {"kernel": named, "wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "achieved_per_s": rate,
-            "peak_per_s": VALU_ISSUE_PEAK, "frac": rate / VALU_ISSUE_PEAK,
+            "peak_per_s": VALU_ISSUE_PEAK, "frac": rate / VALU_ISSUE_PEAK, "simd_valu_busy": simd_valu_busy(pmc),
             "lane_utilisation": pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]),
             "wait_share": pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"] if "SQ_WAIT_ANY" in pmc else None,
             "hbm_traffic_bytes_per_launch": (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc else None,

@@ -50,6 +50,11 @@ def test_committed_counters_are_readable():
     assert bench.pmc_summary(10_000_000, True, "pc_trace_pool_kernel") is None and bench.valu_issue(None, 27.0) is None
     v = bench.valu_issue(s, 27.0)
     assert 0.5 < v["frac"] < 1.0 and 0.3 < v["lane_utilisation"] < 0.8
+    # the vector pipes' busy share from the counters alone (no clock frequency): the headline kernel saturates them
+    assert 0.85 < v["simd_valu_busy"] < 1.0
+    for name, lo, hi in (("ne291", 0.7, 0.9), ("ellip291", 0.65, 0.9), ("leak", 0.2, 0.5)):
+        with open(os.path.join(ROOT, "profiles", "r04", name + "_pmc_summary.json")) as f:
+            assert lo < bench.simd_valu_busy(json.load(f)) < hi, name
 
 
 def test_host_cpu_description():
