@@ -4,7 +4,8 @@ capillaries), random sources (uniform / divergent, near / far, shifted), 1 / 3 /
   (a) explicit photons: certified march == literal march, bit for bit;
   (b) explicit photons: kernel == host compile of the device header, bit for bit;
   (c) source runs: lane, pool and producer kernels (one energy), immediate and logged sweeps (40 energies): same counters, exact sums, planes;
-  (d) source run against the oracle: counters equal, weights to 1e-8 (reported, the trace is chaotic in the last bits).
+  (d) source run against the oracle: started photons, reflections, summed weight within the chaos noise;
+  (e) every second optic with leak_calc=true (40 keV, near divergent source): certified wall search == literal stepping, kernel == host compile, event for event.
 TEST INFRASTRUCTURE (imports the oracle): tests/test_gpu_fuzz.py runs it; by hand  python tests/fuzz_optics.py [n_cases] [seed] [--debug]"""
 import os
 import sys
@@ -12,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
-def run(n_cases=24, seed=20260405, debug=False, out=lambda line: print(line, flush=True)):
+def run(n_cases=24, seed=20260405, debug=False, out=lambda line: print(line, flush=True), leak_every=2):
     """Returns the number of cases with a remark; one line per case goes to `out`."""
     import polycap_amd as pa
     from oracle import pyoracle as oracle
@@ -22,12 +23,12 @@ def run(n_cases=24, seed=20260405, debug=False, out=lambda line: print(line, flu
     oracle.build()
     bad = 0
     for case in range(n_cases):
-        bad += _one_case(case, rng, pa, oracle, pyemul, GLASS, PIN_E, PIN_AMU, PIN_SCATF, synthetic_constants, debug, out)
+        bad += _one_case(case, rng, pa, oracle, pyemul, GLASS, PIN_E, PIN_AMU, PIN_SCATF, synthetic_constants, debug, out, leak_every)
     out("cases with remarks: %d of %d" % (bad, n_cases))
     return bad
 
 
-def _one_case(case, rng, pa, oracle, pyemul, GLASS, PIN_E, PIN_AMU, PIN_SCATF, synthetic_constants, debug, out):
+def _one_case(case, rng, pa, oracle, pyemul, GLASS, PIN_E, PIN_AMU, PIN_SCATF, synthetic_constants, debug, out, leak_every):
     nmax = int(rng.choice([100, 400, 999]))
     n_cap = int(rng.choice([2, 7, 61, 1027, 20419, 200000]))
     L = rng.uniform(2., 12.)
@@ -142,6 +143,38 @@ def _one_case(case, rng, pa, oracle, pyemul, GLASS, PIN_E, PIN_AMU, PIN_SCATF, s
         so, sg = float(np.sum(ot["sum_weights"])), float(np.sum(r0["sum_weights"]))
         if so > 0 and abs(sg - so) > 2*tol*so:
             notes.append("(d) summed weight device %.6g oracle %.6g" % (sg, so))
+    if leak_every and case % leak_every == 0:
+        # (e) leak_calc=true on the same optic: explicit photons, kernel == host compile event for event (geometry bit for bit,
+        # weights with exp(-mu d) to 1e-12), certified wall search == literal stepping bit for bit
+        # hard photons (40 keV: mu ~ 0.9 / cm, walls are transparent) from a near, divergent source: wall crossings by the hundred
+        src_l = (5., sx, sy, 0.02, 0.02, 0., 0., 0.5)
+        a40, s40 = synthetic_constants(np.array([40.0]))
+        prob = pa.Problem(z, cap, ext, sig_rough, n_cap, GLASS["density"], np.array([40.0]), a40, s40, *src_l)
+        with pa.TraceContext(prob) as ctx:
+            ph = ctx.sample_photons(13, np.arange(600))
+            ph = ph[np.isfinite(ph[:, :9]).all(axis=1)]
+            m = len(ph)
+            g = ctx.launch_photons(ph[:m, 0:3], ph[:m, 3:6], ph[:m, 6:9], leak_calc=True)
+            gext, gint = ctx.leaks()
+            ctx.set_option("literal_march", 1)
+            gl = ctx.launch_photons(ph[:m, 0:3], ph[:m, 3:6], ph[:m, 6:9], leak_calc=True)
+            lext, lint = ctx.leaks()
+        for k in g:
+            if not np.array_equal(g[k], gl[k], equal_nan=True):
+                notes.append("(e) certified != literal with leaks in %s" % k)
+        if gext.shape != lext.shape or gint.shape != lint.shape or not (np.array_equal(gext, lext, equal_nan=True) and np.array_equal(gint, lint, equal_nan=True)):
+            notes.append("(e) certified != literal: leak events %s %s / %s %s" % (gext.shape, gint.shape, lext.shape, lint.shape))
+        e = pyemul.launch_leak(prob, ph[:m, 0:3], ph[:m, 3:6], ph[:m, 6:9])
+        eext, eint = pyemul.sort_leak_records(e["records"])
+        for k in ("rc", "exit_coords", "exit_dir", "i_refl", "d_travel"):
+            if not np.array_equal(g[k], e[k], equal_nan=True):
+                notes.append("(e) kernel != host compile with leaks in %s" % k)
+        for got, exp, nm in ((gext, eext, "ext"), (gint, eint, "int")):
+            if got.shape[0] != exp.shape[0] or not np.array_equal(got[:, 0], exp[:, 0]) or not np.array_equal(got[:, 2:12], exp[:, 4:14], equal_nan=True):
+                notes.append("(e) %sleak events: kernel %d, host compile %d" % (nm, got.shape[0], exp.shape[0]))
+            elif got.shape[0] and not np.allclose(got[:, 12:], exp[:, 14:], rtol=1e-12, atol=0.):
+                notes.append("(e) %sleak weights differ" % nm)
+        tag += " | leaks %d + %d" % (gext.shape[0], gint.shape[0])
     out(tag + " | photons %d, rc %s | started %d exit %d kernels %s | %s" % (
         len(ph), dict(zip(*np.unique(fast["rc"], return_counts=True))), r0["i_start"], r0["i_exit"], [runs[k]["kernel"] for k in names],
         "OK" if not notes else "; ".join(notes)))

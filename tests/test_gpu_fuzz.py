@@ -1,5 +1,6 @@
 """Random optics against the invariants of the trace kernels (tests/fuzz_optics.py): certified == literal march, kernel == host
-compile, lane == pool == producer kernels, logged == immediate sweeps, device ~ oracle -- on profiles, capillary counts, sources and
+compile, lane == pool == producer kernels, logged == immediate sweeps, device ~ oracle, and with leak_calc=true certified wall
+search == literal stepping and kernel == host compile event for event -- on profiles, capillary counts, sources and
 energy grids that no deck of the reference has (mono-capillaries, 7 ... 200000 capillaries, 100 ... 999 segments, bulging and
 waisted optics, near divergent sources, roughness)."""
 import pytest
