@@ -141,7 +141,7 @@ static int pc_group_run_impl(pc_hip_group *g, uint64_t seed, int64_t n_slots, ui
 {
 	if (!g) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_group_run: group must not be NULL");
 	if (n_slots < 1) return pc_fail(PC_HIP_ERR_INVALID, "pc_hip_group_run: n_slots must be >= 1");
-	g->leak_run = leak ? 1 : 0;
+	g->leak_run = 0;                            /* set once every member's leak run has succeeded */
 	const size_t N = g->ctx.size();
 	g->run_slots = n_slots;
 	g->keep_images = keep_images ? 1 : 0;
@@ -185,6 +185,7 @@ static int pc_group_run_impl(pc_hip_group *g, uint64_t seed, int64_t n_slots, ui
 			if (g->ctx[j]->run_pending) (void)pc_hip_transmission_wait(g->ctx[j], nullptr);
 		return pc_fail(status[k], msg[k]);
 	}
+	g->leak_run = leak ? 1 : 0;
 	return PC_HIP_OK;
 }
 

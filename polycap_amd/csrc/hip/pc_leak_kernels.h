@@ -581,10 +581,10 @@ static int pc_leak_collect(pc_hip_ctx *ctx, long long n_slots, bool explicit_mod
 	const int end_bit = 64;
 	/* temporary storage of the library calls: the largest of the three sorts and the prefix sum */
 	size_t tb = 0, t1 = 0;
-	hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const unsigned int *)nullptr, (unsigned int *)nullptr, (const unsigned int *)nullptr, (unsigned int *)nullptr, (int)n, 0, 32, st); tb = std::max(tb, t1);
-	hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const unsigned int *)nullptr, (unsigned int *)nullptr, (int)n, 0, end_bit, st); tb = std::max(tb, t1);
-	hipcub::DeviceRadixSort::SortKeys(nullptr, t1, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (int)n, 0, end_bit, st); tb = std::max(tb, t1);
-	hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (const unsigned int *)nullptr, (unsigned int *)nullptr, (int)n + 1, st); tb = std::max(tb, t1);
+	PC_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const unsigned int *)nullptr, (unsigned int *)nullptr, (const unsigned int *)nullptr, (unsigned int *)nullptr, (int)n, 0, 32, st)); tb = std::max(tb, t1);
+	PC_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const unsigned int *)nullptr, (unsigned int *)nullptr, (int)n, 0, end_bit, st)); tb = std::max(tb, t1);
+	PC_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, t1, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (int)n, 0, end_bit, st)); tb = std::max(tb, t1);
+	PC_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (const unsigned int *)nullptr, (unsigned int *)nullptr, (int)n + 1, st)); tb = std::max(tb, t1);
 	int rc = pc_leak_order_buffers(ctx, n, ostride, tb);
 	if (rc) return rc;
 	char *base = (char *)ctx->d_leak_order_tmp;

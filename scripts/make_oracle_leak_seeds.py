@@ -2,7 +2,8 @@
 """Fixture: totals of the CPU oracle's leak driver (oracle/polycap_oracle_leak.c, the reference's literal algorithm:
 src/polycap-source.c:744-1087 with leak_calc, polycap_capil_trace_wall) on the reference's test optic under uniform illumination,
 for many seeds -- what tests/test_gpu_leak.py::test_leak_driver_against_the_oracle_seed_by_seed needs for per-seed mean +- s.e.
-    python scripts/make_oracle_leak_seeds.py [--jobs 6] [--tiny out.json]   ->  tests/golden/oracle_leak_seeds.json
+    python scripts/make_oracle_leak_seeds.py [--jobs 6] [--tiny out.json] [--extend-seven N]   ->  tests/golden/oracle_leak_seeds.json
+(--extend-seven N: N more seeds for the seven-energy group of the existing fixture)
 (--tiny: 3 seeds x 100 slots and 2 seeds x 50 slots into out.json, to try the test's plumbing: POLYCAP_LEAK_SEEDS_FIXTURE=out.json)
 Runs: 16 seeds x 8000 exit-photon slots at 10 keV (the leak bench's workload; 6 CPU-minutes per seed) and 4 seeds x 4000 slots on
 the seven energies of the reference's source test (tests/source.c:216-222: 1, 5, 10, 15, 20, 25, 30 keV).  The optical constants
@@ -54,6 +55,18 @@ def main():
               dict(name="seven_energies", energies=E7, amu=[float(x) for x in a7], scatf=[float(x) for x in s7],
                    seeds=list(range(30000, 30004)), n=4000)]
     block = 1000
+    extend = int(sys.argv[sys.argv.index("--extend-seven") + 1]) if "--extend-seven" in sys.argv else 0
+    fixture = os.path.join(ROOT, "tests", "golden", "oracle_leak_seeds.json")
+    if extend:
+        # more seeds for the seven-energy group of the existing fixture (its other runs are kept as they are)
+        with open(fixture) as f:
+            old_doc = json.load(f)
+        have = [r["seed"] for r in old_doc["groups"][1]["runs"]]
+        groups[0]["seeds"] = []
+        groups[1]["seeds"] = list(range(max(have) + 1, max(have) + 1 + extend))
+        for gi in (0, 1):      # the constants the fixture's runs were made with
+            assert groups[gi]["energies"] == old_doc["groups"][gi]["energies"]
+            groups[gi]["amu"], groups[gi]["scatf"] = old_doc["groups"][gi]["amu"], old_doc["groups"][gi]["scatf"]
     if tiny:
         groups[0]["seeds"], groups[0]["n"] = [20000, 20001, 20002], 100
         groups[1]["seeds"], groups[1]["n"] = [30000, 30001], 50
@@ -92,7 +105,7 @@ def main():
                    "(seed) the totals over its exit-photon slots [0, n): counters = i_exit, not_entered, not_transmitted, sum_irefl",
            "source": [2000., 0.2065, 0.2065, -1., 0., 0., 0., 0.5], "groups": []}
     for gi, g in enumerate(groups):
-        runs = []
+        runs = list(old_doc["groups"][gi]["runs"]) if extend else []
         for seed in g["seeds"]:
             bl = sorted(results[(gi, seed)], key=lambda b: b["slot0"])
             ne = len(g["energies"])
