@@ -5,7 +5,7 @@ for many seeds -- what tests/test_gpu_leak.py::test_leak_driver_against_the_orac
     python scripts/make_oracle_leak_seeds.py [--jobs 6] [--tiny out.json] [--extend-seven N]   ->  tests/golden/oracle_leak_seeds.json
 (--extend-seven N: N more seeds for the seven-energy group of the existing fixture)
 (--tiny: 3 seeds x 100 slots and 2 seeds x 50 slots into out.json, to try the test's plumbing: POLYCAP_LEAK_SEEDS_FIXTURE=out.json)
-Runs: 16 seeds x 8000 exit-photon slots at 10 keV (the leak bench's workload; 6 CPU-minutes per seed) and 4 seeds x 4000 slots on
+Runs: 16 seeds x 8000 exit-photon slots at 10 keV (the leak bench's workload; 6 CPU-minutes per seed) and 4 (+ 4 by --extend-seven: 8) seeds x 4000 slots on
 the seven energies of the reference's source test (tests/source.c:216-222: 1, 5, 10, 15, 20, 25, 30 keV).  The optical constants
 each run used are stored with it: the device test feeds the same numbers."""
 import json

@@ -282,12 +282,12 @@ def test_leak_driver_totals_against_the_oracle_fixture(pa, oracle, optic, leaks)
 
 def test_leak_driver_against_the_oracle_seed_by_seed(pa, optic):
     """tests/golden/oracle_leak_seeds.json (scripts/make_oracle_leak_seeds.py): the CPU oracle's leak driver -- the reference's
-    literal algorithm -- for 16 seeds x 8000 exit-photon slots at 10 keV (the leak bench's workload) and 4 seeds x 4000 slots on
+    literal algorithm -- for 16 seeds x 8000 exit-photon slots at 10 keV (the leak bench's workload) and 8 seeds x 4000 slots on
     the seven energies of the reference's source test, with the optical constants each group used.  Identical photon streams;
     the trajectories are chaotic, so the kernel agrees statistically: per quantity -- started photons,
     efficiency, numbers and summed weights of both kinds of leak event, per energy -- the per-seed deltas (device - oracle, in
     units of the oracle's mean over the seeds) must be consistent with zero: |mean| below the two-sided 0.1 % point of Student's
-    t for the group's number of seeds (4.07 standard errors for 16 seeds, 12.9 for 4; the headline's fixture has 128 seeds and
+    t for the group's number of seeds (4.07 standard errors for 16 seeds, 5.41 for 8; the headline's fixture has 128 seeds and
     uses 3) -- and, whatever the noise, below 1 % + that.  The noise constants c = std(delta) sqrt(N_started per seed) are
     printed.  A bias of the certified wall search would show here."""
     import json
