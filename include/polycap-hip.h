@@ -101,11 +101,13 @@ POLYCAP_EXTERN void pc_hip_ctx_destroy(pc_hip_ctx *ctx);
  *                      a plain pre-pass of the same slots, the heaviest n/400 to lanes of their own (default 1; 0 = slot order)
  *   "leak_heavy_lanes", "leak_heavy_every"   which lanes the heaviest slots go to: lanes 0 .. n-1 of every m-th wave (defaults 1, 1)
  *   "leak_slot_units"  leak_calc source runs keep the units of work per slot (pc_hip_leak_slot_units)
- *   "batch_reflections" source runs with more than 32 energies: 1 (default) reflections are logged (24 B each) and a photon's
+ *   "batch_reflections" source runs with more than 8 energies: 1 (default) reflections are logged (24 B each) and a photon's
  *                      weights swept once per log (any energy count whose sums and constants leave room in LDS for a log per
  *                      wave: to ~1400), 0 every reflection sweeps the weights at once
  *   "log_cap"          reflections per log of the logging kernel (1..255; default 0 = 64 from 64 energies on, 32 below, halved
  *                      while a log per wave does not fit beside the constants of more than ~450 energies)
+ *   "log_min_energies" fewest energies of a source run that logs its reflections (default 9 = every run whose weights are
+ *                      not in registers; >= 9)
  *   "sweep_skip"       histogram-only runs of the logging kernel stop multiplying a weight once it is below 2^-64 (it adds
  *                      nothing to the exact sums any more; default 1)
  *   "flush_max"        the logging kernel lets up to this many finished photons of a wave wait for a common sweep (default 8; the
@@ -224,7 +226,7 @@ POLYCAP_EXTERN int pc_hip_phase_stats(pc_hip_ctx *ctx, int64_t stats[6]);
 /* Which kernel traced the last source run: 0 one photon per lane (pc_trace_kernel), 1 LDS photon pool (option "pool"),
  * 2 launching wave per workgroup (option "producer"; by default chosen when the photons of the context's last run made at
  * least 4 segment visits (reflections, mostly; absorbed photons included) per launch -- a first run of 2e6 slots or more is preceded by a 32768-slot probe),
- * 3 one wave per photon (experiment builds only), 4 logged reflections (pc_trace_log_kernel: source runs with more than 32
+ * 3 one wave per photon (experiment builds only), 4 logged reflections (pc_trace_log_kernel: source runs with more than 8
  * energies, option "batch_reflections" 1), 5 leak_calc runs (pc_leak_kernel; explicit-photon leak launches included).  -1: none yet. */
 POLYCAP_EXTERN int pc_hip_last_kernel(pc_hip_ctx *ctx);
 /* The weight sweeps of the last run when pc_trace_log_kernel traced it: stats = {wave-level passes over 64 (photon, energy)

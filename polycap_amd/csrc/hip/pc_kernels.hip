@@ -258,7 +258,7 @@ __device__ __forceinline__ int pc_reflect_energy_sweep(const pc_energy_const &ec
  * source; PC_MODE_SRC_CIRCULAR / _GENERIC: photons are sampled from the source (circular / elliptical). */
 enum { PC_MODE_SRC_CIRCULAR = 0, PC_MODE_SRC_GENERIC = 1, PC_MODE_EXPLICIT = 2 };
 
-/* Source runs with more than 32 energies have a kernel of their own: pc_trace_log_kernel (pc_sweep_kernel.h). */
+/* Source runs with more than 8 energies have a kernel of their own: pc_trace_log_kernel (pc_sweep_kernel.h). */
 template <int NE, int MODE, int PITCH>
 __global__ void __launch_bounds__(PC_BLOCK, NE == 0 ? PC_MIN_WAVES_NE0 : PC_MIN_WAVES)
 pc_trace_kernel(pc_kargs a)
@@ -933,12 +933,14 @@ struct pc_hip_ctx {
 	int event_march = 0;
 	int pool_new_min = 48;
 	int lds_ec = 1;                /* many-energy runs: per-energy constants in LDS, one 1024-thread workgroup per CU */
-	int batch_reflections = 1;     /* more than 32 energies, source runs: 1 = reflections are logged and a photon's weights swept once per log
+	int batch_reflections = 1;     /* more than 8 energies, source runs: 1 = reflections are logged and a photon's weights swept once per log
 	                                * (pc_sweep_kernel.h), 0 = every reflection sweeps the weights at once */
 	int log_cap = 0;               /* option "log_cap": reflections per log of pc_trace_log_kernel; 0 = 64 from 64 energies on, 32 below (shorter logs
 	                                * leave room in LDS for the logs of more photons per sweep, which few energies need to fill their passes) */
 	int sweep_skip = 1;            /* option "sweep_skip": histogram-only log runs stop multiplying a weight below 2^-64 */
 	int flush_max = 8;             /* option "flush_max": at most this many finished photons of a wave wait for a common sweep */
+	int log_min_energies = 9;      /* option "log_min_energies": source runs with at least this many energies log their reflections (9: every run whose
+	                                * weights are not in registers; measured 9 ... 100 energies: +2 ... +130 % against the immediate sweep) */
 	int sweep_fuse = 1;            /* option "sweep_fuse": histogram-only log runs add a finished photon's weights to the sums in its sweep; 2 = also when
 	                                * its proxies are dead, so that photons the sweep finds dead exercise the take-back pass (tests) */
 	double *d_rlog = nullptr;
@@ -1140,7 +1142,7 @@ static void pc_sweep_certificate(pc_hip_ctx *ctx)
 	ctx->sweep_cert = 1;
 }
 
-/* pc_trace_log_kernel applies to source runs with more than 32 valid energies on a profile of up to 1024 points whose sums and
+/* pc_trace_log_kernel applies to source runs with more than 8 valid energies on a profile of up to 1024 points whose sums and
  * constants fit in LDS beside a stage of at least one log per wave; returns the stage size (doubles per wave), 0 if not */
 static size_t pc_log_stage_doubles(const pc_hip_ctx *ctx, int ne, int log_cap)
 {
@@ -1204,9 +1206,9 @@ static int pc_launch_kernel(pc_hip_ctx *ctx, pc_kargs &a, long long n_items)
 		if (c.valid == 0.) all_valid = false;
 		if (c.rough_c != 0.) a.sweep_rough = 1;
 	}
-	/* source runs with more than 32 (valid) energies log their reflections (pc_trace_log_kernel); an explicit photon reports its
+	/* source runs with more than 8 (valid) energies log their reflections (pc_trace_log_kernel); an explicit photon reports its
 	 * state at the absorbing reflection, which the logging kernel's speculation overwrites */
-	const bool want_log = kne == 0 && ctx->lds_ec && ctx->host.pm.nmax + 1 <= 1024 && ne > 32 && ctx->batch_reflections && all_valid
+	const bool want_log = kne == 0 && ctx->lds_ec && ctx->host.pm.nmax + 1 <= 1024 && ne >= ctx->log_min_energies && ctx->batch_reflections && all_valid
 	                      && MODE != PC_MODE_EXPLICIT;
 	if constexpr (MODE != PC_MODE_EXPLICIT) {
 #ifdef PC_EXPERIMENTS
@@ -1491,6 +1493,7 @@ int pc_hip_set_option(pc_hip_ctx *ctx, const char *name, int64_t value)
 	else if (n == "batch_reflections") ctx->batch_reflections = value ? 1 : 0;
 	else if (n == "log_cap") { if (value < 0 || value > 255) return pc_fail(PC_HIP_ERR_INVALID, "log_cap must be in [0,255] (0 = automatic)"); ctx->log_cap = (int)value; }
 	else if (n == "sweep_skip") ctx->sweep_skip = value ? 1 : 0;
+	else if (n == "log_min_energies") { if (value < 9) return pc_fail(PC_HIP_ERR_INVALID, "log_min_energies must be >= 9 (up to 8 energies have their weights in registers)"); ctx->log_min_energies = (int)value; }
 	else if (n == "flush_max") { if (value < 1 || value > 16) return pc_fail(PC_HIP_ERR_INVALID, "flush_max must be in [1,16]"); ctx->flush_max = (int)value; }
 	else if (n == "sweep_fuse") { if (value < 0 || value > 2) return pc_fail(PC_HIP_ERR_INVALID, "sweep_fuse must be 0, 1 or 2"); ctx->sweep_fuse = (int)value; }
 	else if (n == "plane_images") ctx->plane_images = value ? 1 : 0;

@@ -1,5 +1,5 @@
 /*
- * pc_sweep_kernel.h -- the trace kernel of source runs with many energies (more than 32): reflections are LOGGED and the
+ * pc_sweep_kernel.h -- the trace kernel of source runs with many energies (more than 8: whenever the weights do not fit in registers): reflections are LOGGED and the
  * weights of a photon are swept once per log, with the weight of a (photon, energy) pair in a register across all the
  * logged reflections.  Included by pc_kernels.hip.
  *

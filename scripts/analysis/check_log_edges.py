@@ -1,4 +1,4 @@
-"""Logging kernel at the edges of its range: 33 energies (the fewest), 448 / 449 (where the immediate kernel's constants stop
+"""Logging kernel at the edges of its range: 33 energies, 448 / 449 (where the immediate kernel's constants stop
 fitting in LDS), 700 ... 1400 (the log capacity is halved until a log per wave fits beside the constants; beyond that the immediate
 sweep runs), log capacities 1 ... 255: counters and exact sums equal the immediate sweep's."""
 import sys

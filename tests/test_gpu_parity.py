@@ -510,7 +510,7 @@ def test_pool_and_producer_kernels_are_bit_identical(pa, oracle):
 
 
 def test_logged_reflections_equal_the_immediate_sweep(pa):
-    """Beyond 32 energies a source run logs its reflections (24 B each) and sweeps a photon's weights once per log, the photon
+    """Beyond 8 energies a source run logs its reflections (24 B each) and sweeps a photon's weights once per log, the photon
     flying on meanwhile (pc_trace_log_kernel, option batch_reflections, default on).  On the C3 deck counters, exact sums, every
     exit weight and every image plane equal those of the immediate sweep bit for bit, with images kept and -- where weights below
     2^-64 are no longer multiplied -- in histogram-only runs, for several log capacities.  On the C5 deck with roughness the
@@ -545,15 +545,17 @@ def test_logged_reflections_equal_the_immediate_sweep(pa):
 
 
 def test_logged_reflections_over_the_range_of_energy_counts(pa):
-    """The logging kernel serves every energy count above 32 whose sums and constants leave room in LDS for one log per wave: 33,
-    449 (the immediate kernel's constants no longer fit in LDS there, it reads them from memory), 1000 (the log capacity is halved
-    to fit beside 56 KB of sums and constants).  Counters and exact sums equal the immediate sweep's; images kept at 1000."""
+    """The logging kernel serves every energy count above 8 whose sums and constants leave room in LDS for one log per wave: 9
+    and 20 (a sweep round gathers several photons to fill a pass of 64 lanes), 33, 449 (the immediate kernel's constants no longer
+    fit in LDS there, it reads them from memory), 1000 (the log capacity is halved to fit beside 56 KB of sums and constants).
+    Counters and exact sums equal the immediate sweep's; images kept at 9, 20 and 1000; option log_min_energies restores the
+    immediate sweep below a count."""
     import os
     from tests.conftest import EXAMPLE
-    for ne in (33, 449, 1000):
+    for ne in (9, 20, 33, 449, 1000):
         prob = pa.problem_from_inp(os.path.join(EXAMPLE, "xos1.inp"), energies=np.linspace(2.0, 40.0, ne))
         with pa.TraceContext(prob) as ctx:
-            keep = ne == 1000
+            keep = ne in (9, 20, 1000)
             ctx.set_option("batch_reflections", 0)
             a = ctx.transmission(5, 3, 12000, keep_images=keep)
             assert ctx.last_kernel() == "pc_trace_kernel"
@@ -565,6 +567,11 @@ def test_logged_reflections_over_the_range_of_energy_counts(pa):
             if keep:
                 assert np.array_equal(a["exit_weights"], b["exit_weights"])
                 assert np.array_equal(a["images"], b["images"], equal_nan=True)
+            if ne == 20:
+                ctx.set_option("log_min_energies", 21)
+                c = ctx.transmission(5, 3, 12000, keep_images=keep)
+                assert ctx.last_kernel() == "pc_trace_kernel"
+                assert np.array_equal(a["sumw_fixed"], c["sumw_fixed"]) and np.array_equal(a["images"], c["images"], equal_nan=True)
 
 
 def test_logged_reflections_with_photons_that_die(pa, oracle):
